@@ -1,0 +1,187 @@
+/* trayracer_hip.h -- C ABI of the MI355X (gfx950) render backend for Trayracer's src/raytracer hot path.
+ *
+ * The reference has no FFI/plugin interface.  The seam this library replaces is the pair of Rust calls
+ *     Raytracer::new(scene, delta, max_depth)                 (src/raytracer/mod.rs:37)
+ *     Raytracer::render(&self, (x,y), (w,h), anti_aliasing)   (src/raytracer/mod.rs:218)
+ * made only from RenderingThread::run (src/raytracer/render.rs:105,132), i.e. the body of the block loop
+ * (render.rs:103-152).  Each entry point below cites what it stands in for.  INTEGRATION.md shows the Rust
+ * shim + build.rs lines a maintainer would add.
+ *
+ * Rules of the boundary: plain pointers and sizes only; every pointer passed IN is borrowed for the
+ * duration of the call; opaque handles are owned by the library; no entry point aborts -- all return
+ * TRR_OK (0) or a negative trr_status and leave a message for trr_last_error().  One process drives one
+ * GPU; multi-GPU rendering = one process (rank) per GPU, each rendering its shard of the reference's own
+ * 20x20 block grid (render.rs:103-110) and one gather of the RGB8 strips (see trr_render_shard_device).
+ */
+#ifndef TRAYRACER_HIP_H
+#define TRAYRACER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trr_ctx trr_ctx;       /* device, stream, work buffers */
+typedef struct trr_scene trr_scene;   /* device-resident flattened scene (BVH nodes, triangle records, materials ...) */
+
+typedef enum trr_status {
+    TRR_OK = 0,
+    TRR_ERR_INVALID = -1,      /* bad argument */
+    TRR_ERR_RESOLUTION = -2,   /* width or height < 20: the reference divides by zero at render.rs:109 */
+    TRR_ERR_DEVICE = -3,       /* HIP error (message has the HIP error string) */
+    TRR_ERR_CANCELLED = -4,    /* cancel flag observed; blocks rendered so far are valid, the rest are black */
+    TRR_ERR_NOMEM = -5
+} trr_status;
+
+/* src/scene/material.rs:5-15.  has_* flags are the reference's Option<..>::is_some(). */
+#define TRR_MAT_HAS_KD 1u
+#define TRR_MAT_HAS_KS 2u
+#define TRR_MAT_HAS_NS 4u
+#define TRR_MAT_HAS_DISSOLVE 8u
+typedef struct trr_material_desc {
+    float kd[3];          /* diffuse_color */
+    float ks[3];          /* specular_color */
+    float ns;             /* specular_exponent */
+    float dissolve;       /* 1 - d  (object.rs:106) */
+    int32_t illum;        /* IlluminationModel 0..10 (material.rs:31-53) */
+    int32_t texture;      /* index into the textures array, -1 = no map_Kd */
+    uint32_t flags;       /* TRR_MAT_HAS_* */
+} trr_material_desc;
+
+/* 8-bit RGB image, row-major, as image::RgbImage after into_rgb8() (object.rs:31-38, skybox.rs:57). */
+typedef struct trr_image_rgb8 {
+    const uint8_t* rgb;
+    uint32_t width, height;
+} trr_image_rgb8;
+
+/* One Object (src/scene/object.rs:19-29).  `triangles` is n_triangles x 24 floats laid out like Triangle
+ * (src/scene/triangle.rs:9-21): a, b, c, a_normal, b_normal, c_normal (3 each), a_uv, b_uv, c_uv (2 each).
+ * `material_index` (nullable = all None) holds the object-local index into `materials`, -1 = None.
+ * Triangle ID = (object index, row in `triangles`).
+ * `transform` / `inverse` are Object::transform().to_homogeneous() (object.rs:177-182) and its inverse,
+ * column-major 4x4 exactly as nalgebra stores them (Matrix4::as_slice()), computed by the HOST's own math
+ * so the device inherits the host's bits; trr_object_matrices() is a restatement for non-Rust hosts. */
+typedef struct trr_object_desc {
+    const float* triangles;
+    const int32_t* material_index;
+    uint32_t n_triangles;
+    const trr_material_desc* materials;
+    uint32_t n_materials;
+    float transform[16];
+    float inverse[16];
+} trr_object_desc;
+
+/* src/scene/light.rs:5-9 (color is the already-normalised Ke, light.rs:33). */
+typedef struct trr_light {
+    float position[3];
+    float color[3];
+    float intensity;
+} trr_light;
+
+/* src/scene/settings.rs:4-12 + skybox.rs:6-9.  `seed` feeds the counter RNG that replaces the
+ * irreproducible thread-local rand::random() of raytracer/mod.rs:234,238. */
+typedef struct trr_settings {
+    float ambient_color[3];      /* normalised (settings.rs:51-54) */
+    float ambient_intensity;
+    int32_t skybox_is_image;     /* 0: skybox_color, 1: skybox_image */
+    float skybox_color[3];
+    trr_image_rgb8 skybox_image;
+    int32_t anti_aliasing;
+    uint32_t samples;
+    uint64_t seed;
+} trr_settings;
+
+/* src/scene/camera.rs:5-11 (fov in radians). */
+typedef struct trr_camera {
+    float position[3];
+    float look_at[3];
+    float up[3];
+    float fov;
+    uint32_t width, height;
+} trr_camera;
+
+/* Per-render statistics (the reference only keeps wall ms, render.rs:189-190). */
+typedef struct trr_stats {
+    uint64_t rays_primary;         /* closest-hit queries for camera rays */
+    uint64_t rays_shadow;          /* one per (shaded hit x light) */
+    uint64_t rays_reflection;      /* one per reflective shaded hit below max_depth */
+    uint64_t rays_march;           /* extra queries from the 0.05-step transparency march (mod.rs:100-111) */
+    uint64_t node_visits;          /* filled only when counters were requested */
+    uint64_t tri_tests;
+    uint64_t box_tests;
+    double ms_total;               /* host wall clock around the block loop (what render.rs:96,189 times) */
+    double ms_trace;               /* HIP-event time of all trace-kernel launches */
+    double ms_shade;               /* HIP-event time of the hit-setup + resolve launches */
+    uint32_t trace_launches;
+    uint32_t blocks_rendered;
+} trr_stats;
+
+typedef void (*trr_progress_cb)(void* user, uint32_t blocks_done, uint32_t blocks_total);
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* Replaces nothing in the reference (it has no device).  Selects GPU `device_id` for this process. */
+int trr_create(int device_id, trr_ctx** out);
+void trr_destroy(trr_ctx* ctx);
+/* Last error text of `ctx` (or of the calling thread when ctx is NULL).  Never NULL. */
+const char* trr_last_error(const trr_ctx* ctx);
+
+/* ---- scene upload --------------------------------------------------------------------------- */
+/* Replaces Scene::clone() + Bvh::build (render.rs:60, object.rs:156): flattens all objects into one
+ * BVH4 node array (128-B nodes), leaf-ordered 64-B triangle records, a 64-B interpolation record per
+ * triangle, a material table and a texture atlas in HBM. */
+int trr_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_objects,
+                     const trr_image_rgb8* textures, uint32_t n_textures, trr_scene** out);
+void trr_scene_destroy(trr_scene* scene);
+/* Cheap per-render state the UI edits between renders (ui/properties.rs). */
+int trr_scene_set_instances(trr_scene* scene, const float* transforms, const float* inverses, uint32_t n_objects);
+int trr_scene_set_lights(trr_scene* scene, const trr_light* lights, uint32_t n_lights);
+int trr_scene_set_settings(trr_scene* scene, const trr_settings* settings);
+int trr_scene_set_camera(trr_scene* scene, const trr_camera* camera);
+
+/* ---- render --------------------------------------------------------------------------------- */
+#define TRR_FLAG_COUNTERS 1u   /* also count node visits / box tests / triangle tests (slower kernel build) */
+
+/* Replaces the block loop of RenderingThread::run (render.rs:103-152) for the whole frame: writes
+ * row-major RGB8 (width*height*3, remainder strip left 0,0,0 as render.rs:100-102) into host memory.
+ * hit_obj_out / hit_tri_out (nullable, width*height u32 each, 0xFFFFFFFF = miss) receive the primary ray's
+ * first closest hit for the parity tests (1 spp only).  `cancel_flag` (nullable) is polled between block
+ * batches like render.rs:113,154; `progress` (nullable) is called after each batch (render.rs:143-149). */
+int trr_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t flags,
+               uint8_t* rgb_out, uint32_t* hit_obj_out, uint32_t* hit_tri_out,
+               const volatile int32_t* cancel_flag, trr_progress_cb progress, void* user, trr_stats* stats_out);
+
+/* Multi-GPU form: renders the blocks b with b % n_shards == shard (row-major block ids over the grid of
+ * render.rs:109-110) into a compact DEVICE strip: block j-th owned -> bytes [j*bw*bh*3, (j+1)*bw*bh*3),
+ * row-major inside the block.  All strips have trr_strip_bytes() bytes (the last block slot of a short
+ * shard is zero).  Asynchronous on `stream` (a hipStream_t, NULL = the context's stream) except for the
+ * cancel/progress polling between batches.  One rank per GPU calls this, the strips are gathered to the
+ * root over RCCL (a single ncclGather / torch.distributed.gather), and the root calls trr_assemble_device. */
+int trr_render_shard_device(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t flags,
+                            uint32_t shard, uint32_t n_shards, void* strip_dev, size_t strip_bytes, void* stream,
+                            const volatile int32_t* cancel_flag, trr_progress_cb progress, void* user,
+                            trr_stats* stats_out);
+size_t trr_strip_bytes(uint32_t width, uint32_t height, uint32_t n_shards);
+/* De-interleaves n_shards gathered strips (contiguous, trr_strip_bytes each) into the row-major RGB8 frame
+ * (width*height*3 device bytes; unrendered remainder pixels are zeroed). */
+int trr_assemble_device(trr_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_shards,
+                        const void* strips_dev, void* frame_dev, void* stream);
+/* Blocks until everything queued on the context's stream (or `stream`) has finished. */
+int trr_synchronize(trr_ctx* ctx, void* stream);
+
+/* ---- host math helpers (restatements of nalgebra for non-Rust hosts) -------------------------- */
+/* Object::transform() (object.rs:177-182) and its 4x4 inverse, column-major; rotation = unit quaternion
+ * (i, j, k, w).  Returns 1 when invertible. */
+int trr_object_matrices(const float translation[3], const float rotation[4], const float scale[3],
+                        float transform[16], float inverse[16]);
+/* Camera::ray (camera.rs:30-42) for normalised device coordinates (x, y). */
+void trr_camera_ray(const trr_camera* camera, float x, float y, float origin[3], float direction[3]);
+
+/* Library / device description for logs: "trayracer_hip <version> gfx950 ...". */
+const char* trr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAYRACER_HIP_H */

@@ -1,0 +1,802 @@
+// api.hip -- host side of libtrayracer_hip: context, scene flattening/upload, the per-batch launch
+// sequence, and the extern "C" boundary declared in include/trayracer_hip.h.
+//
+// Mirrors (file:line relative to /root/reference/src):
+//   scene upload      <- Scene::clone + Bvh::build                      raytracer/render.rs:60, scene/object.rs:156
+//   trr_render*       <- RenderingThread::run block loop                raytracer/render.rs:95-193
+//   host math helpers <- Object::transform, Camera::ray (nalgebra)      scene/object.rs:177-182, scene/camera.rs:30-42
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/trayracer_hip.h"
+#include "bvh.h"
+#include "device_types.h"
+#include "launch.h"
+
+namespace trr {
+
+// ---- small host-side fp32 helpers with nalgebra's operation order ([crate]) -------------
+struct H3 {
+    float x, y, z;
+};
+static inline H3 h3(float x, float y, float z) { return H3{x, y, z}; }
+static inline H3 hsub(H3 a, H3 b) { return h3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline H3 hcross(H3 a, H3 b) { return h3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline float hdot(H3 a, H3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float hnorm(H3 a) { return std::sqrt(hdot(a, a)); }
+static inline H3 hdiv(H3 a, float s) { return h3(a.x / s, a.y / s, a.z / s); }
+
+thread_local std::string g_tls_error;
+
+}   // namespace trr
+
+using namespace trr;
+
+// ---- opaque handles --------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct trr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 0;
+    std::string err;
+    std::string desc;
+    // work buffers (grown on demand, kept between renders)
+    uint32_t cap = 0, cap_lights = 0, cap_depth = 0;
+    DevBuf hits, level, term, nlev, occ, shadow_q, chain_q[2], counters, spill, strip, frame, ids_obj, ids_tri, dbg;
+    uint32_t spill_grid = 0;
+    std::vector<hipEvent_t> events;
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+};
+
+struct trr_scene {
+    trr_ctx* ctx = nullptr;
+    DevBuf nodes, tris, interp, objs, mats, texs, texels, lights, sky;
+    std::vector<ObjRec> h_objs;
+    uint32_t n_objs = 0, n_lights = 0, n_mats = 0, n_tex = 0;
+    uint64_t n_nodes = 0, n_tris_total = 0, n_tris_live = 0;
+    uint32_t bvh_depth = 0;
+    trr_settings settings{};
+    bool have_settings = false;
+    uint32_t sky_w = 0, sky_h = 0;
+    trr_camera camera{};
+    bool have_camera = false;
+    float cam_x[3], cam_y[3], cam_z[3], cam_focal = 0.0f;
+};
+
+static int fail(trr_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    g_tls_error = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                                     \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail((ctx), TRR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+static int ensure(trr_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return TRR_OK;
+    if (b.p) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(ctx, TRR_ERR_NOMEM, "hipMalloc(" + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+    }
+    b.bytes = bytes;
+    return TRR_OK;
+}
+static void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+static int upload(trr_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+    int rc = ensure(ctx, b, bytes);
+    if (rc != TRR_OK) return rc;
+    if (bytes) HIPCHK(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return TRR_OK;
+}
+
+// ---- extern "C" ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* trr_version(void) { return "trayracer_hip 0.1 (gfx950, wavefront BVH4 tracer)"; }
+
+const char* trr_last_error(const trr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_tls_error.c_str(); }
+
+int trr_create(int device_id, trr_ctx** out) {
+    if (!out) return fail(nullptr, TRR_ERR_INVALID, "trr_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, TRR_ERR_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, TRR_ERR_INVALID, "trr_create: device_id out of range");
+    trr_ctx* ctx = new trr_ctx();
+    ctx->device = device_id;
+    HIPCHK(ctx, hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, TRR_ERR_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    }
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->desc = std::string(prop.name) + " " + prop.gcnArchName + " CUs=" + std::to_string(prop.multiProcessorCount);
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, TRR_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out = ctx;
+    return TRR_OK;
+}
+
+void trr_destroy(trr_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf* b : {&ctx->hits, &ctx->level, &ctx->term, &ctx->nlev, &ctx->occ, &ctx->shadow_q, &ctx->chain_q[0],
+                      &ctx->chain_q[1], &ctx->counters, &ctx->spill, &ctx->strip, &ctx->frame, &ctx->ids_obj, &ctx->ids_tri,
+                      &ctx->dbg})
+        release(*b);
+    for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int trr_synchronize(trr_ctx* ctx, void* stream) {
+    if (!ctx) return fail(nullptr, TRR_ERR_INVALID, "trr_synchronize: ctx is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    return TRR_OK;
+}
+
+// ---- host math -----------------------------------------------------------------------------------------------
+// Object::transform() = Isometry3::from_parts(t, q).to_homogeneous() * Scale3.to_homogeneous() (object.rs:177-182),
+// inverse by nalgebra's 4x4 cofactor routine [crate: do_inverse4 == MESA gluInvertMatrix].
+int trr_object_matrices(const float translation[3], const float rotation[4], const float scale3[3], float transform[16],
+                        float inverse[16]) {
+    // [crate] UnitQuaternion::to_rotation_matrix
+    const float i = rotation[0], j = rotation[1], k = rotation[2], w = rotation[3];
+    const float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+    const float ij = i * j * 2.0f, wk = w * k * 2.0f, wj = w * j * 2.0f, ik = i * k * 2.0f, jk = j * k * 2.0f, wi = w * i * 2.0f;
+    float iso[16] = {0}, sc[16] = {0};   // column-major: element (r, c) at [c*4 + r]
+    iso[0] = ww + ii - jj - kk; iso[4] = ij - wk;           iso[8] = wj + ik;
+    iso[1] = wk + ij;           iso[5] = ww - ii + jj - kk; iso[9] = jk - wi;
+    iso[2] = ik - wj;           iso[6] = wi + jk;           iso[10] = ww - ii - jj + kk;
+    iso[12] = translation[0]; iso[13] = translation[1]; iso[14] = translation[2]; iso[15] = 1.0f;
+    sc[0] = scale3[0]; sc[5] = scale3[1]; sc[10] = scale3[2]; sc[15] = 1.0f;
+    // [crate] small static Matrix*Matrix: per output column a gemv accumulating column by column
+    float* m = transform;
+    for (int c = 0; c < 4; ++c) {
+        for (int r = 0; r < 4; ++r) m[c * 4 + r] = iso[0 * 4 + r] * sc[c * 4 + 0];
+        for (int q = 1; q < 4; ++q)
+            for (int r = 0; r < 4; ++r) m[c * 4 + r] = iso[q * 4 + r] * sc[c * 4 + q] + m[c * 4 + r];
+    }
+    float o[16];
+    o[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] -
+           m[13] * m[7] * m[10];
+    o[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] +
+           m[12] * m[7] * m[10];
+    o[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] -
+           m[12] * m[7] * m[9];
+    o[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] +
+            m[12] * m[6] * m[9];
+    o[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] +
+           m[13] * m[3] * m[10];
+    o[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] -
+           m[12] * m[3] * m[10];
+    o[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] +
+           m[12] * m[3] * m[9];
+    o[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] -
+            m[12] * m[2] * m[9];
+    o[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] -
+           m[13] * m[3] * m[6];
+    o[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] +
+           m[12] * m[3] * m[6];
+    o[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] -
+            m[12] * m[3] * m[5];
+    o[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] +
+            m[12] * m[2] * m[5];
+    o[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] +
+           m[9] * m[3] * m[6];
+    o[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] -
+           m[8] * m[3] * m[6];
+    o[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] +
+            m[8] * m[3] * m[5];
+    o[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] -
+            m[8] * m[2] * m[5];
+    float det = m[0] * o[0] + m[1] * o[4] + m[2] * o[8] + m[3] * o[12];
+    if (det == 0.0f) {
+        std::memcpy(inverse, transform, 16 * sizeof(float));
+        return 0;
+    }
+    float inv_det = 1.0f / det;
+    for (int q = 0; q < 16; ++q) inverse[q] = o[q] * inv_det;
+    return 1;
+}
+
+// camera basis of Rotation3::look_at_rh(look_at - position, up) [crate] (camera.rs:35)
+static void camera_basis(const trr_camera* c, float x[3], float y[3], float z[3], float* focal) {
+    H3 dir = hsub(h3(c->look_at[0], c->look_at[1], c->look_at[2]), h3(c->position[0], c->position[1], c->position[2]));
+    H3 nd = h3(-dir.x, -dir.y, -dir.z);
+    H3 zax = hdiv(nd, hnorm(nd));
+    H3 xc = hcross(h3(c->up[0], c->up[1], c->up[2]), zax);
+    H3 xax = hdiv(xc, hnorm(xc));
+    H3 yc = hcross(zax, xax);
+    H3 yax = hdiv(yc, hnorm(yc));
+    x[0] = xax.x; x[1] = xax.y; x[2] = xax.z;
+    y[0] = yax.x; y[1] = yax.y; y[2] = yax.z;
+    z[0] = zax.x; z[1] = zax.y; z[2] = zax.z;
+    *focal = -1.0f / std::tan(c->fov / 2.0f);   // camera.rs:32
+}
+
+void trr_camera_ray(const trr_camera* camera, float x, float y, float origin[3], float direction[3]) {
+    float bx[3], by[3], bz[3], focal;
+    camera_basis(camera, bx, by, bz, &focal);
+    H3 dc = h3(x, -y, focal);
+    H3 d = h3(hdot(h3(bx[0], by[0], bz[0]), dc), hdot(h3(bx[1], by[1], bz[1]), dc), hdot(h3(bx[2], by[2], bz[2]), dc));
+    d = hdiv(d, hnorm(d));
+    origin[0] = camera->position[0]; origin[1] = camera->position[1]; origin[2] = camera->position[2];
+    direction[0] = d.x; direction[1] = d.y; direction[2] = d.z;
+}
+
+// ---- scene ----------------------------------------------------------------------------------------------------
+static void fill_obj_matrices(ObjRec& o, const float* fwd_cm, const float* inv_cm) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+            o.fwd[r * 4 + c] = fwd_cm[c * 4 + r];
+            o.inv[r * 4 + c] = inv_cm[c * 4 + r];
+        }
+}
+
+int trr_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_objects, const trr_image_rgb8* textures,
+                     uint32_t n_textures, trr_scene** out) {
+    if (!ctx || !out) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: NULL argument");
+    *out = nullptr;
+    if (n_objects && !objects) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: objects is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    std::vector<Node4> nodes;
+    std::vector<TriRec> tris;
+    std::vector<InterpRec> interp;
+    std::vector<ObjRec> objs(n_objects);
+    std::vector<MatRec> mats;
+    uint32_t depth_max = 0;
+    uint64_t n_total = 0;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+
+    for (uint32_t oi = 0; oi < n_objects; ++oi) {
+        const trr_object_desc& d = objects[oi];
+        if (d.n_triangles && !d.triangles) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: object without triangles pointer");
+        if (d.n_materials && !d.materials) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: object without materials pointer");
+        const uint32_t nt = d.n_triangles;
+        const uint32_t mat_base = (uint32_t)mats.size();
+        for (uint32_t m = 0; m < d.n_materials; ++m) {
+            const trr_material_desc& s = d.materials[m];
+            MatRec r{};
+            for (int k = 0; k < 3; ++k) { r.kd[k] = s.kd[k]; r.ks[k] = s.ks[k]; }
+            r.ns = s.ns; r.dissolve = s.dissolve; r.illum = s.illum;
+            r.tex = (s.texture >= 0 && (uint32_t)s.texture < n_textures) ? s.texture : -1;
+            r.flags = s.flags;
+            mats.push_back(r);
+        }
+        // per-triangle: normal/len (triangle.rs:54-56), own box (triangle.rs:88-95), interpolation record
+        std::vector<TriRec> recs(nt);
+        std::vector<Box3> boxes(nt);
+        std::vector<uint8_t> live(nt);
+        const size_t interp_base = interp.size();
+        interp.resize(interp_base + nt);
+        float maxabs = 0.0f;
+        auto prep = [&](uint32_t lo, uint32_t hi, float* maxabs_out) {
+            float ma = 0.0f;
+            for (uint32_t t = lo; t < hi; ++t) {
+                const float* f = d.triangles + (size_t)t * 24;
+                H3 a = h3(f[0], f[1], f[2]), b = h3(f[3], f[4], f[5]), c = h3(f[6], f[7], f[8]);
+                H3 cr = hcross(hsub(b, a), hsub(c, a));
+                float len = hnorm(cr);
+                H3 n = hdiv(cr, len);
+                TriRec& r = recs[t];
+                r.ax = a.x; r.ay = a.y; r.az = a.z; r.bx = b.x; r.by = b.y; r.bz = b.z; r.cx = c.x; r.cy = c.y; r.cz = c.z;
+                r.nx = n.x; r.ny = n.y; r.nz = n.z;
+                r.tri_id = t;
+                int32_t mi = d.material_index ? d.material_index[t] : -1;
+                r.mat = (mi >= 0 && (uint32_t)mi < d.n_materials) ? (int32_t)(mat_base + (uint32_t)mi) : -1;
+                r.len = len;
+                r.flags = 0;
+                if (r.mat >= 0) {
+                    int il = mats[r.mat].illum;
+                    if (il == 6 || il == 7) r.flags |= 1u;   // material.rs:51-53
+                }
+                // a triangle with |ab x ac| == 0 can never be hit for any delta >= 0 (triangle.rs:56): left out of the tree
+                live[t] = !(len <= 0.0f);
+                H3 c2 = h3(c.x + 0.0001f, c.y + 0.0001f, c.z + 0.0001f);
+                Box3& bx = boxes[t];
+                bx.lo[0] = std::fmin(std::fmin(a.x, b.x), c2.x); bx.lo[1] = std::fmin(std::fmin(a.y, b.y), c2.y);
+                bx.lo[2] = std::fmin(std::fmin(a.z, b.z), c2.z);
+                bx.hi[0] = std::fmax(std::fmax(a.x, b.x), c2.x); bx.hi[1] = std::fmax(std::fmax(a.y, b.y), c2.y);
+                bx.hi[2] = std::fmax(std::fmax(a.z, b.z), c2.z);
+                for (int k = 0; k < 9; ++k) {
+                    float v = std::fabs(f[k]);
+                    if (std::isfinite(v) && v > ma) ma = v;
+                }
+                InterpRec& ip = interp[interp_base + t];
+                for (int k = 0; k < 3; ++k) { ip.na[k] = f[9 + k]; ip.nb[k] = f[12 + k]; ip.nc[k] = f[15 + k]; }
+                ip.uva[0] = f[18]; ip.uva[1] = f[19]; ip.uvb[0] = f[20]; ip.uvb[1] = f[21]; ip.uvc[0] = f[22]; ip.uvc[1] = f[23];
+                ip.pad = 0.0f;
+            }
+            *maxabs_out = ma;
+        };
+        {
+            unsigned nth = nt > (1u << 16) ? std::min(hw, 32u) : 1u;
+            std::vector<float> mas(nth, 0.0f);
+            std::vector<std::thread> th;
+            for (unsigned k = 0; k < nth; ++k) {
+                uint32_t lo = (uint32_t)((uint64_t)nt * k / nth), hi = (uint32_t)((uint64_t)nt * (k + 1) / nth);
+                if (nth == 1) prep(lo, hi, &mas[k]);
+                else th.emplace_back(prep, lo, hi, &mas[k]);
+            }
+            for (auto& t : th) t.join();
+            for (float v : mas) maxabs = std::max(maxabs, v);
+        }
+        std::vector<Box3> live_boxes;
+        std::vector<uint32_t> live_ids;
+        live_boxes.reserve(nt);
+        live_ids.reserve(nt);
+        for (uint32_t t = 0; t < nt; ++t)
+            if (live[t]) { live_boxes.push_back(boxes[t]); live_ids.push_back(t); }
+        BuildResult br;
+        build_bvh4(live_boxes.data(), (uint32_t)live_boxes.size(), 0, &br);
+        const uint32_t node_base = (uint32_t)nodes.size();
+        const uint32_t slot_base = (uint32_t)tris.size();
+        if ((uint64_t)slot_base + live_boxes.size() >= (1ull << 29))
+            return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: more than 2^29 triangles");
+        auto fix = [&](uint32_t ref) -> uint32_t {
+            if (ref == REF_EMPTY) return ref;
+            if (ref & REF_LEAF) {
+                uint32_t first = (ref & 0x7FFFFFFFu) >> 2, cnt = (ref & 3u) + 1u;
+                return make_leaf_ref(first + slot_base, cnt);
+            }
+            return ref + node_base;
+        };
+        for (Node4 nd : br.nodes) {
+            for (int k = 0; k < 4; ++k) nd.child[k] = fix(nd.child[k]);
+            nodes.push_back(nd);
+        }
+        for (uint32_t s = 0; s < br.order.size(); ++s) tris.push_back(recs[live_ids[br.order[s]]]);
+        ObjRec& o = objs[oi];
+        std::memset(&o, 0, sizeof o);
+        fill_obj_matrices(o, d.transform, d.inverse);
+        o.root = fix(br.root_ref);
+        o.tri_base = (uint32_t)interp_base;
+        o.n_tris = nt;
+        o.flags = (nt == 1) ? 1u : 0u;   // [crate] a root Leaf is returned by traverse() without a box test
+        o.slack_abs = 1.0e-4f * maxabs;
+        depth_max = std::max(depth_max, br.max_depth);
+        n_total += nt;
+    }
+
+    trr_scene* sc = new trr_scene();
+    sc->ctx = ctx;
+    sc->n_objs = n_objects;
+    sc->h_objs = objs;
+    sc->n_nodes = nodes.size();
+    sc->n_tris_total = n_total;
+    sc->n_tris_live = tris.size();
+    sc->bvh_depth = depth_max;
+    sc->n_mats = (uint32_t)mats.size();
+    sc->n_tex = n_textures;
+    // texture atlas
+    std::vector<TexRec> texs(n_textures);
+    std::vector<uint8_t> texels;
+    for (uint32_t t = 0; t < n_textures; ++t) {
+        if (!textures[t].rgb || textures[t].width == 0 || textures[t].height == 0) {
+            delete sc;
+            return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: empty texture");
+        }
+        texs[t].offset = texels.size();
+        texs[t].w = textures[t].width;
+        texs[t].h = textures[t].height;
+        size_t nb = (size_t)textures[t].width * textures[t].height * 3;
+        texels.insert(texels.end(), textures[t].rgb, textures[t].rgb + nb);
+    }
+    int rc = TRR_OK;
+    if ((rc = upload(ctx, sc->nodes, nodes.data(), nodes.size() * sizeof(Node4))) != TRR_OK ||
+        (rc = upload(ctx, sc->tris, tris.data(), tris.size() * sizeof(TriRec))) != TRR_OK ||
+        (rc = upload(ctx, sc->interp, interp.data(), interp.size() * sizeof(InterpRec))) != TRR_OK ||
+        (rc = upload(ctx, sc->objs, objs.data(), objs.size() * sizeof(ObjRec))) != TRR_OK ||
+        (rc = upload(ctx, sc->mats, mats.data(), mats.size() * sizeof(MatRec))) != TRR_OK ||
+        (rc = upload(ctx, sc->texs, texs.data(), texs.size() * sizeof(TexRec))) != TRR_OK ||
+        (rc = upload(ctx, sc->texels, texels.data(), texels.size())) != TRR_OK) {
+        trr_scene_destroy(sc);
+        return rc;
+    }
+    *out = sc;
+    return TRR_OK;
+}
+
+void trr_scene_destroy(trr_scene* sc) {
+    if (!sc) return;
+    if (sc->ctx) (void)hipSetDevice(sc->ctx->device);
+    if (sc->ctx && sc->ctx->stream) (void)hipStreamSynchronize(sc->ctx->stream);
+    for (DevBuf* b : {&sc->nodes, &sc->tris, &sc->interp, &sc->objs, &sc->mats, &sc->texs, &sc->texels, &sc->lights, &sc->sky})
+        release(*b);
+    delete sc;
+}
+
+int trr_scene_set_instances(trr_scene* sc, const float* transforms, const float* inverses, uint32_t n_objects) {
+    if (!sc || !transforms || !inverses) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_set_instances: NULL argument");
+    if (n_objects != sc->n_objs) return fail(sc->ctx, TRR_ERR_INVALID, "trr_scene_set_instances: object count mismatch");
+    HIPCHK(sc->ctx, hipSetDevice(sc->ctx->device));
+    HIPCHK(sc->ctx, hipStreamSynchronize(sc->ctx->stream));
+    for (uint32_t i = 0; i < n_objects; ++i) fill_obj_matrices(sc->h_objs[i], transforms + 16 * i, inverses + 16 * i);
+    return upload(sc->ctx, sc->objs, sc->h_objs.data(), sc->h_objs.size() * sizeof(ObjRec));
+}
+
+int trr_scene_set_lights(trr_scene* sc, const trr_light* lights, uint32_t n_lights) {
+    if (!sc || (n_lights && !lights)) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_set_lights: NULL argument");
+    if (n_lights > 0xFFFFu) return fail(sc->ctx, TRR_ERR_INVALID, "trr_scene_set_lights: more than 65535 lights");
+    HIPCHK(sc->ctx, hipSetDevice(sc->ctx->device));
+    HIPCHK(sc->ctx, hipStreamSynchronize(sc->ctx->stream));
+    std::vector<LightRec> l(n_lights);
+    for (uint32_t i = 0; i < n_lights; ++i) {
+        for (int k = 0; k < 3; ++k) { l[i].pos[k] = lights[i].position[k]; l[i].color[k] = lights[i].color[k]; }
+        l[i].intensity = lights[i].intensity;
+        l[i].pad = 0.0f;
+    }
+    sc->n_lights = n_lights;
+    return upload(sc->ctx, sc->lights, l.data(), l.size() * sizeof(LightRec));
+}
+
+int trr_scene_set_settings(trr_scene* sc, const trr_settings* s) {
+    if (!sc || !s) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_set_settings: NULL argument");
+    HIPCHK(sc->ctx, hipSetDevice(sc->ctx->device));
+    HIPCHK(sc->ctx, hipStreamSynchronize(sc->ctx->stream));
+    sc->settings = *s;
+    sc->settings.skybox_image.rgb = nullptr;   // borrowed pointer: not kept
+    sc->sky_w = sc->sky_h = 0;
+    if (s->skybox_is_image) {
+        if (!s->skybox_image.rgb || !s->skybox_image.width || !s->skybox_image.height)
+            return fail(sc->ctx, TRR_ERR_INVALID, "trr_scene_set_settings: empty skybox image");
+        sc->sky_w = s->skybox_image.width;
+        sc->sky_h = s->skybox_image.height;
+        int rc = upload(sc->ctx, sc->sky, s->skybox_image.rgb, (size_t)sc->sky_w * sc->sky_h * 3);
+        if (rc != TRR_OK) return rc;
+    }
+    sc->have_settings = true;
+    return TRR_OK;
+}
+
+int trr_scene_set_camera(trr_scene* sc, const trr_camera* c) {
+    if (!sc || !c) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_set_camera: NULL argument");
+    sc->camera = *c;
+    camera_basis(c, sc->cam_x, sc->cam_y, sc->cam_z, &sc->cam_focal);
+    sc->have_camera = true;
+    return TRR_OK;
+}
+
+// ---- render -----------------------------------------------------------------------------------------------------
+struct Tiling {
+    uint32_t w, h, bw, bh, nbx, nby, nblocks;
+};
+static bool tiling_of(uint32_t w, uint32_t h, Tiling* t) {
+    t->w = w; t->h = h;
+    t->bw = w / 20; t->bh = h / 20;               // render.rs:103
+    if (t->bw == 0 || t->bh == 0) return false;   // render.rs:109 would divide by zero
+    t->nbx = w / t->bw; t->nby = h / t->bh;       // render.rs:109-110
+    t->nblocks = t->nbx * t->nby;
+    return true;
+}
+static uint32_t owned_blocks(const Tiling& t, uint32_t shard, uint32_t n_shards) {
+    return shard < t.nblocks ? (t.nblocks - shard + n_shards - 1) / n_shards : 0;
+}
+static uint32_t max_owned_blocks(const Tiling& t, uint32_t n_shards) { return (t.nblocks + n_shards - 1) / n_shards; }
+
+size_t trr_strip_bytes(uint32_t width, uint32_t height, uint32_t n_shards) {
+    Tiling t;
+    if (n_shards == 0 || !tiling_of(width, height, &t)) return 0;
+    return (size_t)max_owned_blocks(t, n_shards) * t.bw * t.bh * 3;
+}
+
+static hipEvent_t get_event(trr_ctx* ctx, size_t i) {
+    while (ctx->events.size() <= i) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        ctx->events.push_back(ev);
+    }
+    return ctx->events[i];
+}
+
+// counters block layout (uint32 words): [CW_WORK + i] work counter of the i-th trace launch (i <= max_depth),
+// [CW_NSHADOW + lvl] shadow rays emitted at level lvl, [CW_NCHAIN + lvl] chain rays entering level lvl;
+// the 64-bit kernel counters follow at byte offset CW_WORDS*4.
+enum { CW_WORK = 0, CW_NSHADOW = 288, CW_NCHAIN = 576, CW_WORDS = 1024 };
+
+static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t max_depth, uint32_t flags, uint32_t shard,
+                             uint32_t n_shards, uint8_t* strip_dev, size_t strip_bytes, hipStream_t st, uint32_t* ids_obj_dev,
+                             uint32_t* ids_tri_dev, const volatile int32_t* cancel_flag, trr_progress_cb progress, void* user,
+                             trr_stats* stats) {
+    if (!ctx || !sc) return fail(ctx, TRR_ERR_INVALID, "render: NULL context or scene");
+    if (sc->ctx != ctx) return fail(ctx, TRR_ERR_INVALID, "render: scene belongs to another context");
+    if (!sc->have_camera || !sc->have_settings) return fail(ctx, TRR_ERR_INVALID, "render: camera/settings not set");
+    if (!(delta >= 0.0f)) return fail(ctx, TRR_ERR_INVALID, "render: delta must be >= 0");
+    if (max_depth > 255) return fail(ctx, TRR_ERR_INVALID, "render: max_depth above 255");
+    if (n_shards == 0 || shard >= n_shards) return fail(ctx, TRR_ERR_INVALID, "render: bad shard / n_shards");
+    Tiling tl;
+    if (!tiling_of(sc->camera.width, sc->camera.height, &tl))
+        return fail(ctx, TRR_ERR_RESOLUTION, "render: width and height must be >= 20 (reference divides by zero, render.rs:109)");
+    const size_t need_strip = (size_t)max_owned_blocks(tl, n_shards) * tl.bw * tl.bh * 3;
+    if (!strip_dev || strip_bytes < need_strip) return fail(ctx, TRR_ERR_INVALID, "render: strip buffer too small");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    auto wall0 = std::chrono::steady_clock::now();
+
+    const bool aa = sc->settings.anti_aliasing != 0;
+    const uint32_t spp = aa ? sc->settings.samples : 1u;
+    const uint32_t L = sc->n_lights;
+    const uint32_t n_owned = owned_blocks(tl, shard, n_shards);
+    const uint32_t bpix = tl.bw * tl.bh;
+    const bool count = (flags & TRR_FLAG_COUNTERS) != 0;
+
+    HIPCHK(ctx, hipMemsetAsync(strip_dev, 0, need_strip, st));
+    trr_stats zero{};
+    if (stats) *stats = zero;
+    if (spp == 0 || n_owned == 0) {
+        // mod.rs:228-249 with samples == 0: the mean of nothing is NaN, which quantises to 0 (render.rs:136)
+        if (stats) stats->blocks_rendered = n_owned;
+        return TRR_OK;
+    }
+    if ((uint64_t)bpix * spp > (1ull << 31)) return fail(ctx, TRR_ERR_INVALID, "render: block too large for one batch");
+
+    // ---- batch sizing ---------------------------------------------------------------------------------------
+    const uint64_t per_sample = 32 /*hits*/ + 4ull * LEVEL_PLANES * std::max(1u, max_depth) + 12 + 1 +
+                                4ull * L * std::max(1u, max_depth) + 32ull * L + 64;
+    const uint64_t budget = 24ull << 30;
+    uint64_t max_samples = std::min<uint64_t>(budget / per_sample, 1ull << 25);
+    const uint64_t spb = (uint64_t)bpix * spp;
+    uint32_t blocks_per_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_owned, max_samples / spb));
+    const uint32_t cap = (uint32_t)(((uint64_t)blocks_per_batch * spb + 63) & ~63ull);
+    const uint32_t D = std::max(1u, max_depth);
+    int rc;
+    if ((rc = ensure(ctx, ctx->hits, (size_t)cap * sizeof(HitRec))) || (rc = ensure(ctx, ctx->level, (size_t)cap * 4 * LEVEL_PLANES * D)) ||
+        (rc = ensure(ctx, ctx->term, (size_t)cap * 12)) || (rc = ensure(ctx, ctx->nlev, (size_t)cap)) ||
+        (rc = ensure(ctx, ctx->occ, (size_t)cap * 4 * std::max(1u, L) * D)) ||
+        (rc = ensure(ctx, ctx->shadow_q, (size_t)cap * sizeof(RayRec) * std::max(1u, L))) ||
+        (rc = ensure(ctx, ctx->chain_q[0], (size_t)cap * sizeof(RayRec))) ||
+        (rc = ensure(ctx, ctx->chain_q[1], (size_t)cap * sizeof(RayRec))) || (rc = ensure(ctx, ctx->counters, CW_WORDS * 4 + 64)))
+        return rc;
+
+    // persistent trace grid: every CU gets as many 256-thread blocks as its registers / LDS admit
+    const int bpc = std::min(trace_blocks_per_cu(true, count), trace_blocks_per_cu(false, count));
+    const uint32_t trace_grid = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::max(1, std::min(bpc, 8));
+    if ((rc = ensure(ctx, ctx->spill, trace_spill_bytes(trace_grid)))) return rc;
+    const uint32_t aux_grid_max = (uint32_t)ctx->n_cu * 8;
+
+    FrameParams fp{};
+    fp.nodes = (const Node4*)sc->nodes.p; fp.tris = (const TriRec*)sc->tris.p; fp.interp = (const InterpRec*)sc->interp.p;
+    fp.objs = (const ObjRec*)sc->objs.p; fp.mats = (const MatRec*)sc->mats.p; fp.texs = (const TexRec*)sc->texs.p;
+    fp.texels = (const uint8_t*)sc->texels.p; fp.lights = (const LightRec*)sc->lights.p;
+    fp.n_objs = sc->n_objs; fp.n_lights = L;
+    for (int k = 0; k < 3; ++k) {
+        fp.ambient[k] = sc->settings.ambient_color[k];
+        fp.sky_color[k] = sc->settings.skybox_color[k];
+        fp.cam_pos[k] = sc->camera.position[k];
+        fp.cam_x[k] = sc->cam_x[k]; fp.cam_y[k] = sc->cam_y[k]; fp.cam_z[k] = sc->cam_z[k];
+    }
+    fp.ambient_intensity = sc->settings.ambient_intensity;
+    fp.sky = sc->settings.skybox_is_image ? (const uint8_t*)sc->sky.p : nullptr;
+    fp.sky_w = sc->sky_w; fp.sky_h = sc->sky_h;
+    fp.aa = aa ? 1u : 0u;
+    fp.spp = spp;
+    {
+        float sq = std::sqrt((float)sc->settings.samples);   // mod.rs:226
+        fp.sqrt_spp = sq >= 4294967296.0f ? 0xFFFFFFFFu : (sq > 0.0f ? (uint32_t)sq : 0u);
+    }
+    fp.seed = sc->settings.seed;
+    fp.cam_focal = sc->cam_focal;
+    fp.width = tl.w; fp.height = tl.h; fp.bw = tl.bw; fp.bh = tl.bh; fp.nbx = tl.nbx; fp.nby = tl.nby;
+    fp.shard = shard; fp.n_shards = n_shards;
+    fp.delta = delta; fp.max_depth = max_depth;
+
+    uint32_t* cw = (uint32_t*)ctx->counters.p;
+    unsigned long long* kc = (unsigned long long*)((char*)ctx->counters.p + CW_WORDS * 4);
+    const uint32_t n_batches = (n_owned + blocks_per_batch - 1) / blocks_per_batch;
+    // pinned readback area: per batch CW_WORDS words + 8 kernel counters
+    const size_t rb_stride = CW_WORDS * 4 + 64;
+    if (ctx->pinned_bytes < rb_stride * n_batches) {
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        HIPCHK(ctx, hipHostMalloc(&ctx->pinned, rb_stride * n_batches, hipHostMallocDefault));
+        ctx->pinned_bytes = rb_stride * n_batches;
+    }
+    const bool timed = stats != nullptr;
+    size_t n_events = 0;
+    std::vector<uint8_t> ev_kind;   // 0 trace, 1 shade
+    auto ev_begin = [&](uint8_t kind) {
+        if (!timed) return;
+        hipEvent_t e = get_event(ctx, n_events);
+        if (e) (void)hipEventRecord(e, st);
+        ++n_events;
+        ev_kind.push_back(kind);
+    };
+    auto ev_end = [&]() {
+        if (!timed) return;
+        hipEvent_t e = get_event(ctx, n_events);
+        if (e) (void)hipEventRecord(e, st);
+        ++n_events;
+    };
+
+    uint32_t blocks_done = 0;
+    int result = TRR_OK;
+    uint32_t batches_run = 0;
+    for (uint32_t bi = 0; bi < n_batches; ++bi) {
+        if (cancel_flag && *cancel_flag) { result = TRR_ERR_CANCELLED; break; }   // render.rs:113
+        BatchParams bp{};
+        bp.first_owned = bi * blocks_per_batch;
+        bp.n_blocks = std::min(blocks_per_batch, n_owned - bp.first_owned);
+        bp.n_pixels = bp.n_blocks * bpix;
+        bp.n_samples = bp.n_pixels * spp;
+        bp.cap = cap;
+        HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, CW_WORDS * 4 + 64, st));
+        const uint32_t aux_grid = std::min<uint32_t>(aux_grid_max, (bp.n_samples + 255) / 256);
+
+        TraceIO tio{};
+        tio.hits = (HitRec*)ctx->hits.p;
+        tio.occ = (int32_t*)ctx->occ.p;
+        tio.counters = kc;
+        tio.spill = (uint2*)ctx->spill.p;
+        tio.work_counter = cw + CW_WORK + 0;
+        tio.first_obj = ids_obj_dev;
+        tio.first_tri = ids_tri_dev;
+        ev_begin(0);
+        launch_trace(true, count, trace_grid, st, fp, bp, tio);
+        ev_end();
+        for (uint32_t lvl = 0; lvl < max_depth; ++lvl) {
+            SetupIO sio{};
+            sio.chain_in = (const RayRec*)ctx->chain_q[lvl & 1].p;
+            sio.n_chain_in = cw + CW_NCHAIN + lvl;
+            sio.hits = (const HitRec*)ctx->hits.p;
+            sio.level = (float*)ctx->level.p;
+            sio.term = (float*)ctx->term.p;
+            sio.nlev = (uint8_t*)ctx->nlev.p;
+            sio.shadow_out = (RayRec*)ctx->shadow_q.p;
+            sio.n_shadow_out = cw + CW_NSHADOW + lvl;
+            sio.chain_out = (RayRec*)ctx->chain_q[(lvl + 1) & 1].p;
+            sio.n_chain_out = cw + CW_NCHAIN + lvl + 1;
+            ev_begin(1);
+            launch_setup(lvl == 0, aux_grid, st, fp, bp, sio, lvl);
+            ev_end();
+            TraceIO t2 = tio;
+            t2.shadow_q = (const RayRec*)ctx->shadow_q.p;
+            t2.n_shadow = cw + CW_NSHADOW + lvl;
+            t2.chain_q = (const RayRec*)ctx->chain_q[(lvl + 1) & 1].p;
+            t2.n_chain = cw + CW_NCHAIN + lvl + 1;
+            t2.work_counter = cw + CW_WORK + lvl + 1;
+            t2.first_obj = nullptr;
+            t2.first_tri = nullptr;
+            ev_begin(0);
+            launch_trace(false, count, trace_grid, st, fp, bp, t2);
+            ev_end();
+        }
+        ResolveIO rio{};
+        rio.level = (const float*)ctx->level.p; rio.term = (const float*)ctx->term.p; rio.nlev = (const uint8_t*)ctx->nlev.p;
+        rio.occ = (const int32_t*)ctx->occ.p; rio.strip = strip_dev;
+        ev_begin(1);
+        launch_resolve(std::min<uint32_t>(aux_grid_max, (bp.n_pixels + 255) / 256), st, fp, bp, rio);
+        ev_end();
+        HIPCHK(ctx, hipGetLastError());
+        if (stats) HIPCHK(ctx, hipMemcpyAsync((char*)ctx->pinned + rb_stride * bi, ctx->counters.p, rb_stride, hipMemcpyDeviceToHost, st));
+        ++batches_run;
+        blocks_done += bp.n_blocks;
+        if (progress || cancel_flag) {
+            HIPCHK(ctx, hipStreamSynchronize(st));   // blocks of this batch are final: render.rs:143-149
+            if (progress) progress(user, blocks_done, n_owned);
+        }
+    }
+    if (stats) {
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        for (uint32_t bi = 0; bi < batches_run; ++bi) {
+            const uint32_t* w = (const uint32_t*)((char*)ctx->pinned + rb_stride * bi);
+            const unsigned long long* k = (const unsigned long long*)((char*)ctx->pinned + rb_stride * bi + CW_WORDS * 4);
+            uint32_t first = bi * blocks_per_batch;
+            uint32_t nb = std::min(blocks_per_batch, n_owned - first);
+            stats->rays_primary += (uint64_t)nb * bpix * spp;
+            for (uint32_t lvl = 0; lvl < max_depth; ++lvl) {
+                stats->rays_shadow += w[CW_NSHADOW + lvl];
+                stats->rays_reflection += w[CW_NCHAIN + lvl + 1];
+            }
+            stats->node_visits += k[0]; stats->box_tests += k[1]; stats->tri_tests += k[2]; stats->rays_march += k[3];
+        }
+        for (size_t i = 0; i + 1 < n_events; i += 2) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ctx->events[i], ctx->events[i + 1]) == hipSuccess) {
+                if (ev_kind[i / 2] == 0) { stats->ms_trace += ms; stats->trace_launches++; }
+                else stats->ms_shade += ms;
+            }
+        }
+        stats->blocks_rendered = blocks_done;
+        stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
+    if (result == TRR_ERR_CANCELLED) return fail(ctx, result, "render cancelled");
+    return result;
+}
+
+int trr_render_shard_device(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t flags, uint32_t shard,
+                            uint32_t n_shards, void* strip_dev, size_t strip_bytes, void* stream,
+                            const volatile int32_t* cancel_flag, trr_progress_cb progress, void* user, trr_stats* stats_out) {
+    if (!ctx) return fail(nullptr, TRR_ERR_INVALID, "trr_render_shard_device: ctx is NULL");
+    return render_shard_impl(ctx, scene, delta, max_depth, flags, shard, n_shards, (uint8_t*)strip_dev, strip_bytes,
+                             stream ? (hipStream_t)stream : ctx->stream, nullptr, nullptr, cancel_flag, progress, user, stats_out);
+}
+
+int trr_assemble_device(trr_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_shards, const void* strips_dev, void* frame_dev,
+                        void* stream) {
+    if (!ctx || !strips_dev || !frame_dev) return fail(ctx, TRR_ERR_INVALID, "trr_assemble_device: NULL argument");
+    Tiling t;
+    if (n_shards == 0) return fail(ctx, TRR_ERR_INVALID, "trr_assemble_device: n_shards is 0");
+    if (!tiling_of(width, height, &t)) return fail(ctx, TRR_ERR_RESOLUTION, "trr_assemble_device: width and height must be >= 20");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    launch_assemble(stream ? (hipStream_t)stream : ctx->stream, width, height, t.bw, t.bh, t.nbx, t.nby, n_shards,
+                    trr_strip_bytes(width, height, n_shards), (const uint8_t*)strips_dev, (uint8_t*)frame_dev);
+    HIPCHK(ctx, hipGetLastError());
+    return TRR_OK;
+}
+
+int trr_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t flags, uint8_t* rgb_out,
+               uint32_t* hit_obj_out, uint32_t* hit_tri_out, const volatile int32_t* cancel_flag, trr_progress_cb progress,
+               void* user, trr_stats* stats_out) {
+    if (!ctx || !scene || !rgb_out) return fail(ctx, TRR_ERR_INVALID, "trr_render: NULL argument");
+    if (!scene->have_camera) return fail(ctx, TRR_ERR_INVALID, "trr_render: camera not set");
+    const uint32_t w = scene->camera.width, h = scene->camera.height;
+    Tiling t;
+    if (!tiling_of(w, h, &t)) return fail(ctx, TRR_ERR_RESOLUTION, "trr_render: width and height must be >= 20 (render.rs:109)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t sb = trr_strip_bytes(w, h, 1), fb = (size_t)w * h * 3;
+    int rc;
+    if ((rc = ensure(ctx, ctx->strip, sb)) || (rc = ensure(ctx, ctx->frame, fb))) return rc;
+    const bool ids = hit_obj_out && hit_tri_out;
+    if (ids) {
+        if ((rc = ensure(ctx, ctx->ids_obj, (size_t)w * h * 4)) || (rc = ensure(ctx, ctx->ids_tri, (size_t)w * h * 4))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->ids_obj.p, 0xFF, (size_t)w * h * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->ids_tri.p, 0xFF, (size_t)w * h * 4, ctx->stream));
+    }
+    int rres = render_shard_impl(ctx, scene, delta, max_depth, flags, 0, 1, (uint8_t*)ctx->strip.p, sb, ctx->stream,
+                                 ids ? (uint32_t*)ctx->ids_obj.p : nullptr, ids ? (uint32_t*)ctx->ids_tri.p : nullptr, cancel_flag,
+                                 progress, user, stats_out);
+    if (rres != TRR_OK && rres != TRR_ERR_CANCELLED) return rres;
+    std::string keep = ctx->err;
+    if ((rc = trr_assemble_device(ctx, w, h, 1, ctx->strip.p, ctx->frame.p, ctx->stream))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(rgb_out, ctx->frame.p, fb, hipMemcpyDeviceToHost, ctx->stream));
+    if (ids) {
+        HIPCHK(ctx, hipMemcpyAsync(hit_obj_out, ctx->ids_obj.p, (size_t)w * h * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hit_tri_out, ctx->ids_tri.p, (size_t)w * h * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (rres == TRR_ERR_CANCELLED) return fail(ctx, rres, keep);
+    return TRR_OK;
+}
+
+}   // extern "C"

@@ -1,0 +1,252 @@
+// bvh.cpp -- binned-SAH binary build (parallel over subtrees) collapsed to 128-byte 4-wide nodes.
+// See bvh.h for why the tree's shape is free (reference call site: src/scene/object.rs:156).
+#include "bvh.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+
+namespace trr {
+namespace {
+
+constexpr int NBINS = 16;
+constexpr uint32_t MAX_LEAF = 4;
+constexpr uint32_t PAR_MIN = 1u << 15;   // subtrees above this size may get their own thread
+
+struct BNode {
+    Box3 box;
+    uint32_t left, right;    // children (valid when count == 0)
+    uint32_t first, count;   // leaf range in idx (count > 0)
+};
+
+inline Box3 empty_box() {
+    const float inf = std::numeric_limits<float>::infinity();
+    return Box3{{inf, inf, inf}, {-inf, -inf, -inf}};
+}
+inline void grow(Box3& a, const Box3& b) {
+    for (int k = 0; k < 3; ++k) {
+        a.lo[k] = std::fmin(a.lo[k], b.lo[k]);
+        a.hi[k] = std::fmax(a.hi[k], b.hi[k]);
+    }
+}
+inline float half_area(const Box3& b) {
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    if (!(dx >= 0.0f) || !(dy >= 0.0f) || !(dz >= 0.0f)) return 0.0f;
+    float a = dx * dy + dy * dz + dz * dx;
+    return std::isfinite(a) ? a : std::numeric_limits<float>::max();
+}
+
+struct Builder {
+    const Box3* boxes;
+    uint32_t n;
+    std::vector<float> cent[3];
+    std::vector<uint32_t> idx;
+    std::vector<BNode> nodes;
+    std::atomic<uint32_t> n_nodes{0};
+    int par_depth = 0;
+
+    uint32_t alloc2() { return n_nodes.fetch_add(2); }
+
+    void make_leaf(BNode& nd, uint32_t lo, uint32_t hi) {
+        nd.first = lo;
+        nd.count = hi - lo;
+        nd.left = nd.right = 0;
+    }
+
+    void build(uint32_t me, uint32_t lo, uint32_t hi, int depth) {
+        BNode& nd = nodes[me];
+        Box3 box = empty_box();
+        float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = lo; i < hi; ++i) {
+            uint32_t t = idx[i];
+            grow(box, boxes[t]);
+            for (int k = 0; k < 3; ++k) {
+                float c = cent[k][t];
+                cmin[k] = std::fmin(cmin[k], c);
+                cmax[k] = std::fmax(cmax[k], c);
+            }
+        }
+        nd.box = box;
+        uint32_t cnt = hi - lo;
+        if (cnt <= 2) { make_leaf(nd, lo, hi); return; }
+
+        // binned SAH over the three axes
+        float best_cost = INFINITY;
+        int best_axis = -1, best_bin = -1;
+        float best_scale = 0.0f;
+        if (depth < 56) {
+            for (int ax = 0; ax < 3; ++ax) {
+                float ext = cmax[ax] - cmin[ax];
+                if (!(ext > 0.0f) || !std::isfinite(ext)) continue;
+                float scale = (float)NBINS / ext;
+                Box3 bb[NBINS];
+                uint32_t bc[NBINS];
+                for (int b = 0; b < NBINS; ++b) { bb[b] = empty_box(); bc[b] = 0; }
+                for (uint32_t i = lo; i < hi; ++i) {
+                    uint32_t t = idx[i];
+                    int b = (int)((cent[ax][t] - cmin[ax]) * scale);
+                    b = b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
+                    bc[b]++;
+                    grow(bb[b], boxes[t]);
+                }
+                float right_area[NBINS];
+                uint32_t right_cnt[NBINS];
+                Box3 acc = empty_box();
+                uint32_t c = 0;
+                for (int b = NBINS - 1; b > 0; --b) {
+                    if (bc[b]) grow(acc, bb[b]);
+                    c += bc[b];
+                    right_area[b] = half_area(acc);
+                    right_cnt[b] = c;
+                }
+                acc = empty_box();
+                c = 0;
+                for (int b = 0; b < NBINS - 1; ++b) {
+                    if (bc[b]) grow(acc, bb[b]);
+                    c += bc[b];
+                    if (c == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = half_area(acc) * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; best_scale = scale; }
+                }
+            }
+        }
+        if (cnt <= MAX_LEAF) {
+            float leaf_cost = half_area(box) * (float)cnt;
+            if (best_axis < 0 || leaf_cost <= best_cost + 1.5f * half_area(box)) { make_leaf(nd, lo, hi); return; }
+        }
+        uint32_t mid = lo;
+        if (best_axis >= 0) {
+            const float c0 = cmin[best_axis];
+            const std::vector<float>& ca = cent[best_axis];
+            auto it = std::partition(idx.begin() + lo, idx.begin() + hi, [&](uint32_t t) {
+                int b = (int)((ca[t] - c0) * best_scale);
+                b = b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
+                return b <= best_bin;
+            });
+            mid = (uint32_t)(it - idx.begin());
+        }
+        if (mid == lo || mid == hi) {
+            // all centroids coincide (or the tree got too deep): split by count on the widest axis
+            int ax = 0;
+            float e0 = cmax[0] - cmin[0], e1 = cmax[1] - cmin[1], e2 = cmax[2] - cmin[2];
+            if (e1 > e0 && e1 >= e2) ax = 1; else if (e2 > e0 && e2 > e1) ax = 2;
+            mid = lo + cnt / 2;
+            const std::vector<float>& ca = cent[ax];
+            std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi,
+                             [&](uint32_t a, uint32_t b) { return ca[a] < ca[b] || (ca[a] == ca[b] && a < b); });
+        }
+        uint32_t kids = alloc2();
+        nd.count = 0;
+        nd.first = 0;
+        nd.left = kids;
+        nd.right = kids + 1;
+        if (depth < par_depth && cnt >= PAR_MIN) {
+            std::thread th([this, kids, lo, mid, depth] { build(kids, lo, mid, depth + 1); });
+            build(kids + 1, mid, hi, depth + 1);
+            th.join();
+        } else {
+            build(kids, lo, mid, depth + 1);
+            build(kids + 1, mid, hi, depth + 1);
+        }
+    }
+};
+
+struct Collapser {
+    const std::vector<BNode>& bn;
+    std::vector<Node4>& out;
+    uint32_t max_depth = 0;
+
+    uint32_t ref_of(uint32_t b, uint32_t depth) {
+        const BNode& nd = bn[b];
+        if (nd.count > 0) return make_leaf_ref(nd.first, nd.count);
+        return emit(b, depth);
+    }
+
+    // emits the 4-wide node whose children are (grand)children of binary node b; returns its index
+    uint32_t emit(uint32_t b, uint32_t depth) {
+        if (depth > max_depth) max_depth = depth;
+        uint32_t me = (uint32_t)out.size();
+        out.emplace_back();
+        uint32_t kids[4];
+        int nk = 2;
+        kids[0] = bn[b].left;
+        kids[1] = bn[b].right;
+        while (nk < 4) {
+            int pick = -1;
+            float pa = -1.0f;
+            for (int k = 0; k < nk; ++k) {
+                if (bn[kids[k]].count > 0) continue;
+                float a = half_area(bn[kids[k]].box);
+                if (a > pa) { pa = a; pick = k; }
+            }
+            if (pick < 0) break;
+            uint32_t p = kids[pick];
+            kids[pick] = bn[p].left;
+            kids[nk++] = bn[p].right;
+        }
+        Node4 nd;
+        std::memset(&nd, 0, sizeof nd);
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int k = 0; k < 4; ++k) {
+            if (k < nk) {
+                const Box3& bx = bn[kids[k]].box;
+                nd.lox[k] = bx.lo[0]; nd.loy[k] = bx.lo[1]; nd.loz[k] = bx.lo[2];
+                nd.hix[k] = bx.hi[0]; nd.hiy[k] = bx.hi[1]; nd.hiz[k] = bx.hi[2];
+            } else {
+                nd.lox[k] = nd.loy[k] = nd.loz[k] = inf;
+                nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -inf;
+                nd.child[k] = REF_EMPTY;
+            }
+        }
+        for (int k = 0; k < nk; ++k) nd.child[k] = ref_of(kids[k], depth + 1);
+        out[me] = nd;
+        return me;
+    }
+};
+
+}   // namespace
+
+void build_bvh4(const Box3* boxes, uint32_t n, uint32_t n_threads, BuildResult* res) {
+    res->nodes.clear();
+    res->order.clear();
+    res->root_ref = REF_EMPTY;
+    res->max_depth = 0;
+    res->bounds = empty_box();
+    if (n == 0) return;
+    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    n_threads = std::min(n_threads, 64u);
+
+    Builder b;
+    b.boxes = boxes;
+    b.n = n;
+    for (int k = 0; k < 3; ++k) b.cent[k].resize(n);
+    b.idx.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        b.idx[i] = i;
+        for (int k = 0; k < 3; ++k) {
+            float c = 0.5f * boxes[i].lo[k] + 0.5f * boxes[i].hi[k];
+            b.cent[k][i] = std::isfinite(c) ? c : 0.0f;   // NaN / infinite vertices must not poison the binning
+        }
+    }
+    b.nodes.resize((size_t)2 * n + 2);
+    b.n_nodes = 1;
+    b.par_depth = 0;
+    while ((1u << b.par_depth) < n_threads) b.par_depth++;
+    b.build(0, 0, n, 0);
+
+    res->order = b.idx;
+    res->bounds = b.nodes[0].box;
+    if (b.nodes[0].count > 0) {
+        res->root_ref = make_leaf_ref(b.nodes[0].first, b.nodes[0].count);
+        return;
+    }
+    res->nodes.reserve((size_t)n / 2 + 16);
+    Collapser c{b.nodes, res->nodes};
+    res->root_ref = c.emit(0, 1);
+    res->max_depth = c.max_depth;
+}
+
+}   // namespace trr

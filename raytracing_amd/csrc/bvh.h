@@ -1,0 +1,43 @@
+// bvh.h -- host-side BVH4 build for the gfx950 traversal kernel.
+//
+// Stands in for bvh::Bvh::build (reference call site: src/scene/object.rs:156).  The reference's crate
+// builds a binary one-shape-per-leaf tree; its traversal returns every triangle whose OWN box
+// (src/scene/triangle.rs:88-95) passes the slab test, and the caller takes a min over exact tests
+// (object.rs:191-206).  That candidate set does not depend on the tree ("candidate-set
+// invariant"), so this builder is free to produce the layout the GPU wants: 4-wide nodes of exactly one
+// 128-B cache line, <= 4 triangles per leaf, triangles re-ordered so that every leaf is contiguous.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace trr {
+
+struct Box3 {
+    float lo[3], hi[3];
+};
+
+// One 128-byte node: SoA child boxes (lo/hi per axis for the 4 children), child references, padding.
+struct alignas(128) Node4 {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    uint32_t child[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(Node4) == 128, "Node4 must be one cache line");
+
+constexpr uint32_t REF_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t REF_LEAF = 0x80000000u;
+// leaf reference: REF_LEAF | (first_slot << 2) | (count - 1), count in 1..4, first_slot < 2^29
+inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return REF_LEAF | (first << 2) | (count - 1); }
+
+struct BuildResult {
+    std::vector<Node4> nodes;      // nodes[0] is the root when root_ref is an inner reference
+    std::vector<uint32_t> order;   // slot -> index into the input box array
+    uint32_t root_ref = REF_EMPTY; // inner node index, leaf reference, or REF_EMPTY
+    uint32_t max_depth = 0;        // depth of the 4-wide tree (root = 1)
+    Box3 bounds{};                 // union of all input boxes
+};
+
+// boxes: one conservative box per primitive.  n_threads = 0 -> hardware concurrency.
+void build_bvh4(const Box3* boxes, uint32_t n, uint32_t n_threads, BuildResult* out);
+
+}   // namespace trr

@@ -1,0 +1,135 @@
+// device_types.h -- HBM layouts shared by the host uploader and the gfx950 kernels.
+#pragma once
+#include <cstdint>
+
+#include "bvh.h"
+
+namespace trr {
+
+// 64-byte leaf-ordered triangle record = what one exact test reads (half a 128-B line; a 4-triangle leaf is
+// two whole lines).  n = (b-a)x(c-a) / |.| and len = |(b-a)x(c-a)| are the values Triangle::intersect
+// recomputes on every call (src/scene/triangle.rs:54-56), precomputed once with identical fp32 operations.
+struct alignas(64) TriRec {
+    float ax, ay, az, bx;
+    float by, bz, cx, cy;
+    float cz, nx, ny, nz;
+    uint32_t tri_id;    // row in the object's triangle array (the reference's Vec order)
+    int32_t mat;        // global material id, -1 = None
+    float len;          // |ab x ac|; the kernel culls len <= delta (triangle.rs:56)
+    uint32_t flags;     // bit0: material is transparent (illum 6/7, material.rs:51-53)
+};
+static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+
+// 64-byte per-triangle interpolation record, indexed by obj.tri_base + tri_id; read once per shaded hit
+// (src/scene/object.rs:201-203).
+struct alignas(64) InterpRec {
+    float na[3], nb[3], nc[3];
+    float uva[2], uvb[2], uvc[2];
+    float pad;
+};
+static_assert(sizeof(InterpRec) == 64, "InterpRec must be 64 bytes");
+
+// Per-object record.  inv/fwd: rows of the 3x4 affine part of Object::transform()^-1 / Object::transform().
+struct ObjRec {
+    float inv[12];      // inv[r*4 + c], c = 3 is the translation column
+    float fwd[12];
+    uint32_t root;      // inner node index (absolute), leaf ref (absolute slots) or REF_EMPTY
+    uint32_t tri_base;  // first InterpRec of this object
+    uint32_t n_tris;    // triangles in the reference's Vec (degenerate ones included)
+    uint32_t flags;     // bit0: single-triangle object -> the crate's traverse() returns it with no box test
+    float slack_abs;    // absolute pruning slack in object units (1e-4 * largest |coordinate|)
+    uint32_t pad[3];
+};
+
+struct MatRec {   // src/scene/material.rs:5-15
+    float kd[3];
+    float ks[3];
+    float ns;
+    float dissolve;
+    int32_t illum;
+    int32_t tex;        // texture id, -1 = none
+    uint32_t flags;     // TRR_MAT_HAS_*
+    uint32_t pad;
+};
+
+struct TexRec {
+    uint64_t offset;    // byte offset into the texel atlas
+    uint32_t w, h;
+};
+
+struct LightRec {   // src/scene/light.rs:5-9
+    float pos[3];
+    float color[3];
+    float intensity;
+    float pad;
+};
+
+// Ray queue entry (32 B).  meta: bits 0..7 level, bit 8 shadow flag, bits 16..31 light index.
+struct alignas(16) RayRec {
+    float ox, oy, oz, dx;
+    float dy, dz;
+    uint32_t sample;
+    uint32_t meta;
+};
+static_assert(sizeof(RayRec) == 32, "RayRec must be 32 bytes");
+
+// Closest-hit result of a chain (camera / reflection) ray, indexed by queue position.
+struct alignas(16) HitRec {
+    float u, v, w;      // barycentric weights of (a, b, c)
+    uint32_t slot;      // TriRec index, 0xFFFFFFFF = miss
+    uint32_t obj;
+    uint32_t tri;       // triangle id (row in the object's triangle array) of the LAST hit of the march
+    uint32_t first_obj; // ids of the FIRST raycast of the march (0xFFFFFFFF = miss)
+    uint32_t first_tri;
+};
+static_assert(sizeof(HitRec) == 32, "HitRec must be 32 bytes");
+
+// Shaded-hit record of one chain level (src/raytracer/mod.rs:124-146 inputs), SoA planes of `cap` samples.
+// plane order: Px Py Pz Nx Ny Nz Dx Dy Dz diffR diffG diffB mat
+constexpr int LEVEL_PLANES = 13;
+
+// Everything a kernel needs about the frame (passed by value).
+struct FrameParams {
+    // scene
+    const Node4* nodes;
+    const TriRec* tris;
+    const InterpRec* interp;
+    const ObjRec* objs;
+    const MatRec* mats;
+    const TexRec* texs;
+    const uint8_t* texels;
+    const LightRec* lights;
+    uint32_t n_objs, n_lights;
+    // settings
+    float ambient[3];
+    float ambient_intensity;
+    float sky_color[3];
+    const uint8_t* sky;       // nullptr = constant colour
+    uint32_t sky_w, sky_h;
+    uint32_t aa;              // anti_aliasing
+    uint32_t spp;             // samples per pixel actually traced (1 when !aa)
+    uint32_t sqrt_spp;        // floor(sqrt(samples)) (mod.rs:226)
+    uint64_t seed;
+    // camera (basis precomputed on the host from the same inputs Camera::ray uses per call)
+    float cam_pos[3];
+    float cam_x[3], cam_y[3], cam_z[3];
+    float cam_focal;          // -1 / tan(fov/2)
+    uint32_t width, height;
+    // tiling (render.rs:103-110)
+    uint32_t bw, bh, nbx, nby;
+    uint32_t shard, n_shards;
+    // tracer
+    float delta;
+    uint32_t max_depth;
+};
+
+// Work description of one batch of owned blocks.
+struct BatchParams {
+    uint32_t first_owned;     // index (among this shard's blocks) of the batch's first block
+    uint32_t n_blocks;        // blocks in the batch
+    uint32_t n_pixels;        // n_blocks * bw * bh
+    uint32_t n_samples;       // n_pixels * spp
+    uint32_t cap;             // plane stride of the per-sample arrays (>= n_samples)
+};
+
+}   // namespace trr
