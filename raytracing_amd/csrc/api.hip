@@ -674,7 +674,8 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         ev_begin(0);
         launch_trace(true, count, trace_grid, st, fp, bp, tio);
         ev_end();
-        for (uint32_t lvl = 0; lvl < max_depth; ++lvl) {
+        // max_depth == 0: one setup pass turns every sample into skybox(ray.direction) (mod.rs:125-127), no secondary rays
+        for (uint32_t lvl = 0; lvl < std::max(1u, max_depth); ++lvl) {
             SetupIO sio{};
             sio.chain_in = (const RayRec*)ctx->chain_q[lvl & 1].p;
             sio.n_chain_in = cw + CW_NCHAIN + lvl;
@@ -689,6 +690,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
             ev_begin(1);
             launch_setup(lvl == 0, aux_grid, st, fp, bp, sio, lvl);
             ev_end();
+            if (max_depth == 0) break;
             TraceIO t2 = tio;
             t2.shadow_q = (const RayRec*)ctx->shadow_q.p;
             t2.n_shadow = cw + CW_NSHADOW + lvl;
@@ -800,3 +802,4 @@ int trr_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, 
 }
 
 }   // extern "C"
+

@@ -79,8 +79,8 @@ struct alignas(16) HitRec {
     uint32_t slot;      // TriRec index, 0xFFFFFFFF = miss
     uint32_t obj;
     uint32_t tri;       // triangle id (row in the object's triangle array) of the LAST hit of the march
-    uint32_t first_obj; // ids of the FIRST raycast of the march (0xFFFFFFFF = miss)
-    uint32_t first_tri;
+    uint32_t pad0;      // (the first-raycast ids go straight to the id buffers)
+    uint32_t pad1;
 };
 static_assert(sizeof(HitRec) == 32, "HitRec must be 32 bytes");
 

@@ -164,9 +164,51 @@ DEV F3 primary_dir(const FrameParams& fp, uint32_t x, uint32_t y, uint32_t si) {
 constexpr int TRACE_THREADS = 256;
 constexpr int STACK_LDS = 16;       // per-lane (ref, tmin) entries kept in LDS
 constexpr int STACK_SPILL = 48;     // further entries in a per-thread HBM spill area (rarely touched)
-constexpr int REFILL_MIN = 20;      // re-fill when at least this many of the 64 lanes are idle
-constexpr float PRUNE_REL = 1.0e-3f;
+#ifndef TRR_REFILL_MIN
+#define TRR_REFILL_MIN 20
+#endif
+constexpr int REFILL_MIN = TRR_REFILL_MIN;      // re-fill when at least this many of the 64 lanes are idle
+#ifndef TRR_PRUNE_REL
+#define TRR_PRUNE_REL 1.0e-3f
+#endif
+constexpr float PRUNE_REL = TRR_PRUNE_REL;
 
+
+// triangle.rs:53-85 + object.rs:201,206 for one 64-B TriRec (normal and |ab x ac| precomputed with the same
+// fp32 operations).  One function for the leaf loop AND the end-of-object re-evaluation of the winner, so both
+// produce the same bits.
+struct TriHit {
+    float u, v, w;   // weights of (a, b, c)
+    F3 point;        // a*u + b*v + c*w (object space)
+    float key;       // |o' - point|^2 (object.rs:206)
+};
+DEV bool tri_test(float4 q0, float4 q1, float4 q2, float len, F3 oo, F3 od, float delta, TriHit& h) {
+    F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x), n = f3(q2.y, q2.z, q2.w);
+    if (len <= delta) return false;                              // :56  try_normalize(delta)
+    float t = dot(a - oo, n) / dot(od, n);                       // :58
+    if (t < delta) return false;                                 // :60 (NaN falls through)
+    F3 p = oo + scale(od, t);                                    // :64
+    F3 ab = b - a;
+    F3 ap = p - a, bp_ = p - b, cp = p - c;                      // :66-68
+    float e0 = dot(cross(ab, ap), n);                            // :70,74
+    float e1 = dot(cross(c - b, bp_), n);                        // :71,75
+    float e2 = dot(cross(a - c, cp), n);                         // :72,76
+    if (e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) return false;       // :78
+    float area = e0 + e1 + e2;                                   // :82
+    h.u = e1 / area; h.v = e2 / area; h.w = e0 / area;           // :84
+    h.point = (scale(a, h.u) + scale(b, h.v)) + scale(c, h.w);   // object.rs:201
+    h.key = norm_squared(oo - h.point);                          // object.rs:206
+    return true;
+}
+
+// min_by_key(OrderedFloat) over candidates: NaN is the greatest key; equal keys keep the first candidate, which
+// here (as in the oracle) is the lowest triangle index.
+DEV bool candidate_better(bool have, float key, uint32_t tri, float best_key, uint32_t best_tri) {
+    if (!have) return true;
+    if (is_nan(key)) return is_nan(best_key) && tri < best_tri;
+    if (is_nan(best_key)) return true;
+    return key < best_key || (key == best_key && tri < best_tri);
+}
 
 template <bool RAYGEN, bool COUNT>
 __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchParams bp, TraceIO io) {
@@ -182,29 +224,23 @@ __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchPa
         total = n_shadow + *io.n_chain;
     }
 
-    // ---- per-lane state --------------------------------------------------------------------
+    // ---- per-lane state (results go to memory as soon as a raycast ends; only the winner's slot/key stay live) ----
     bool active = false;
     bool exhausted = false;
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 0);      // world ray (origin advances during the march)
     uint32_t r_out = 0, r_sample = 0, r_meta = 0;
-    bool last_have = false, first_done = false;
-    uint32_t last_slot = 0, last_obj = 0, last_tri = 0, first_slot_obj = 0xFFFFFFFFu, first_tri = 0xFFFFFFFFu;
-    float last_u = 0, last_v = 0, last_w = 0;
-    int32_t last_mat = -1;
+    bool first_cast = true;                      // no raycast of this ray has finished yet
     // one raycast (all objects)
     uint32_t obj_i = 0;
-    bool g_have = false, g_transp = false;
+    bool g_have = false;
     float g_key = 0, g_u = 0, g_v = 0, g_w = 0, t_lim = INFINITY;
-    uint32_t g_slot = 0, g_obj = 0, g_tri = 0;
-    int32_t g_mat = -1;
+    uint32_t g_slot = 0, g_obj = 0;
     // one object
     F3 oo = f3(0, 0, 0), od = f3(0, 0, 0), oi = f3(0, 0, 0);
     float len_d = 1.0f, lim_n = INFINITY, slack_abs = 0.0f;
-    bool o_have = false, o_transp = false, skipbox = false;
-    float o_key = 0, o_u = 0, o_v = 0, o_w = 0;
-    F3 o_point = f3(0, 0, 0);
+    bool o_have = false, skipbox = false;
+    float o_key = 0;
     uint32_t o_slot = 0, o_tri = 0;
-    int32_t o_mat = -1;
     uint32_t cur = REF_EMPTY;
     int sp = 0;
     unsigned long long c_nodes = 0, c_boxes = 0, c_tris = 0, c_march = 0;
@@ -256,10 +292,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchPa
                         r_out = idx - n_shadow;   // meaningful for chain rays only
                     }
                     active = true;
-                    last_have = false;
-                    first_done = false;
-                    first_slot_obj = 0xFFFFFFFFu;
-                    first_tri = 0xFFFFFFFFu;
+                    first_cast = true;
                     obj_i = 0xFFFFFFFFu;   // "before the first object"
                     g_have = false;
                     t_lim = INFINITY;
@@ -278,7 +311,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchPa
             // |point_world - ray.origin| (first object wins ties: strict <, NaN greatest)
             if (o_have) {
                 const ObjRec* ob = fp.objs + obj_i;
-                F3 pw = xform_point(ob->fwd, o_point);
+                const float4* tp = reinterpret_cast<const float4*>(fp.tris + o_slot);
+                float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+                TriHit h;
+                h.u = h.v = h.w = 0.0f; h.point = f3(0, 0, 0); h.key = 0.0f;
+                (void)tri_test(q0, q1, q2, q3.z, oo, od, fp.delta, h);   // same inputs as in the leaf loop -> same bits
+                F3 pw = xform_point(ob->fwd, h.point);
                 float key = norm(pw - ro);
                 bool better;
                 if (!g_have) better = true;
@@ -286,56 +324,62 @@ __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchPa
                 else if (is_nan(g_key)) better = true;
                 else better = key < g_key;
                 if (better) {
-                    g_have = true; g_key = key; g_slot = o_slot; g_obj = obj_i; g_tri = o_tri;
-                    g_u = o_u; g_v = o_v; g_w = o_w; g_mat = o_mat; g_transp = o_transp;
+                    g_have = true; g_key = key; g_slot = o_slot; g_obj = obj_i;
+                    g_u = h.u; g_v = h.v; g_w = h.w;
                     // later objects only need boxes nearer than this hit (ray parameter + slack)
-                    float th = sqrtf(o_key) / len_d;
+                    float th = sqrtf(h.key) / len_d;
                     if (th == th) t_lim = th * (1.0f + PRUNE_REL);
                 }
                 o_have = false;
             }
             ++obj_i;
             if (obj_i >= fp.n_objs) {
-                // raycast done (mod.rs:45-51); raycast_transparent loop (mod.rs:100-111)
+                // raycast done (mod.rs:45-51); raycast_transparent loop (mod.rs:100-111): only .last() is consumed,
+                // so each finished raycast with a hit overwrites the ray's result record
+                const bool is_shadow = !RAYGEN && (r_meta & 0x100u) != 0u;
                 bool again = false;
                 if (g_have) {
-                    last_have = true; last_slot = g_slot; last_obj = g_obj; last_tri = g_tri;
-                    last_u = g_u; last_v = g_v; last_w = g_w;
-                    last_mat = g_mat;
-                    if (!first_done) { first_slot_obj = g_obj; first_tri = g_tri; }
-                    if (g_transp) {
+                    const float4 q3 = reinterpret_cast<const float4*>(fp.tris + g_slot)[3];
+                    const uint32_t tri_id = __float_as_uint(q3.x);
+                    const int32_t mat = (int32_t)__float_as_uint(q3.y);
+                    const bool transp = (__float_as_uint(q3.w) & 1u) != 0u;
+                    if (is_shadow) {
+                        uint32_t level = r_meta & 0xFFu, light = r_meta >> 16;
+                        io.occ[((size_t)level * fp.n_lights + light) * bp.cap + r_sample] = mat >= 0 ? mat : -2;
+                    } else {
+                        float4* dst = reinterpret_cast<float4*>(io.hits + r_out);
+                        dst[0] = make_float4(g_u, g_v, g_w, __uint_as_float(g_slot));
+                        dst[1] = make_float4(__uint_as_float(g_obj), __uint_as_float(tri_id), 0.0f, 0.0f);
+                    }
+                    if (RAYGEN && first_cast && io.first_obj != nullptr) {
+                        io.first_obj[r_sample] = g_obj;
+                        io.first_tri[r_sample] = tri_id;
+                    }
+                    if (transp) {
                         ro = ro + scale(rd, 0.05f);   // mod.rs:106
                         again = true;
                         if (COUNT) c_march++;
                     }
+                } else if (first_cast) {
+                    if (is_shadow) {
+                        uint32_t level = r_meta & 0xFFu, light = r_meta >> 16;
+                        io.occ[((size_t)level * fp.n_lights + light) * bp.cap + r_sample] = -1;
+                    } else {
+                        float4* dst = reinterpret_cast<float4*>(io.hits + r_out);
+                        dst[0] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                        dst[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+                    if (RAYGEN && io.first_obj != nullptr) {
+                        io.first_obj[r_sample] = 0xFFFFFFFFu;
+                        io.first_tri[r_sample] = 0xFFFFFFFFu;
+                    }
                 }
-                first_done = true;
+                first_cast = false;
                 if (again) {
                     obj_i = 0;
                     g_have = false;
                     t_lim = INFINITY;
                 } else {
-                    // ---- ray finished: write the result --------------------------------------------
-                    bool is_shadow = (r_meta & 0x100u) != 0u;
-                    if (!RAYGEN && is_shadow) {
-                        uint32_t level = r_meta & 0xFFu, light = r_meta >> 16;
-                        int32_t code = last_have ? (last_mat >= 0 ? last_mat : -2) : -1;
-                        io.occ[((size_t)level * fp.n_lights + light) * bp.cap + r_sample] = code;
-                    } else {
-                        HitRec h;
-                        h.u = last_u; h.v = last_v; h.w = last_w;
-                        h.slot = last_have ? last_slot : 0xFFFFFFFFu;
-                        h.obj = last_obj;
-                        h.pad[0] = h.pad[1] = h.pad[2] = 0;
-                        float4* dst = reinterpret_cast<float4*>(io.hits + r_out);
-                        dst[0] = make_float4(h.u, h.v, h.w, __uint_as_float(h.slot));
-                        dst[1] = make_float4(__uint_as_float(h.obj), __uint_as_float(last_tri), __uint_as_float(first_slot_obj),
-                                             __uint_as_float(first_tri));
-                        if (RAYGEN && io.first_obj != nullptr) {
-                            io.first_obj[r_sample] = first_slot_obj;
-                            io.first_tri[r_sample] = first_tri;
-                        }
-                    }
                     active = false;
                 }
             }
@@ -403,11 +447,10 @@ __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchPa
             for (uint32_t j = 0; j < cnt; ++j) {
                 const float4* tp = reinterpret_cast<const float4*>(fp.tris + first + j);
                 float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
-                F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x), n = f3(q2.y, q2.z, q2.w);
-                float len = q3.z;
                 if (COUNT) c_boxes++;
                 if (!skipbox) {
                     // triangle.rs:88-95 box (empty.grow(a).grow(b).grow(c + 1e-4)) + [crate] slab test
+                    F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x);
                     F3 c2 = f3(c.x + 0.0001f, c.y + 0.0001f, c.z + 0.0001f);
                     F3 lo = f3(rmin(rmin(a.x, b.x), c2.x), rmin(rmin(a.y, b.y), c2.y), rmin(rmin(a.z, b.z), c2.z));
                     F3 hi = f3(rmax(rmax(a.x, b.x), c2.x), rmax(rmax(a.y, b.y), c2.y), rmax(rmax(a.z, b.z), c2.z));
@@ -420,34 +463,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchPa
                     if (tmin > lim_n) continue;   // cannot beat the current best (slack keeps this conservative)
                 }
                 if (COUNT) c_tris++;
-                // triangle.rs:53-85 with normal = try_normalize(ab x ac, delta) precomputed
-                if (len <= fp.delta) continue;                               // :56
-                float t = dot(a - oo, n) / dot(od, n);                       // :58
-                if (t < fp.delta) continue;                                  // :60 (NaN falls through)
-                F3 p = oo + scale(od, t);                                    // :64
-                F3 ab = b - a;
-                F3 ap = p - a, bp_ = p - b, cp = p - c;                      // :66-68
-                float e0 = dot(cross(ab, ap), n);                            // :70,74
-                float e1 = dot(cross(c - b, bp_), n);                        // :71,75
-                float e2 = dot(cross(a - c, cp), n);                         // :72,76
-                if (e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) continue;           // :78
-                float area = e0 + e1 + e2;                                   // :82
-                float u = e1 / area, v = e2 / area, w = e0 / area;           // :84
-                // object.rs:201,206
-                F3 point = (scale(a, u) + scale(b, v)) + scale(c, w);
-                float key = norm_squared(oo - point);
+                TriHit h;
+                if (!tri_test(q0, q1, q2, q3.z, oo, od, fp.delta, h)) continue;
                 uint32_t tri_id = __float_as_uint(q3.x);
-                bool better;   // min_by_key(OrderedFloat): NaN greatest; equal keys -> lowest triangle index
-                if (!o_have) better = true;
-                else if (is_nan(key)) better = is_nan(o_key) && tri_id < o_tri;
-                else if (is_nan(o_key)) better = true;
-                else better = key < o_key || (key == o_key && tri_id < o_tri);
-                if (better) {
-                    o_have = true; o_key = key; o_slot = first + j; o_tri = tri_id;
-                    o_u = u; o_v = v; o_w = w; o_point = point;
-                    o_mat = (int32_t)__float_as_uint(q3.y);
-                    o_transp = (__float_as_uint(q3.w) & 1u) != 0u;
-                    float dist = sqrtf(key);
+                if (candidate_better(o_have, h.key, tri_id, o_key, o_tri)) {
+                    o_have = true; o_key = h.key; o_slot = first + j; o_tri = tri_id;
+                    float dist = sqrtf(h.key);
                     if (dist == dist) lim_n = rmin(lim_n, dist * (1.0f + PRUNE_REL) + slack_abs);
                 }
             }
@@ -513,8 +534,9 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
             const float4* hp = reinterpret_cast<const float4*>(io.hits + i);
             float4 h0 = hp[0], h1 = hp[1];
             uint32_t slot = __float_as_uint(h0.w);
-            if (slot == 0xFFFFFFFFu) {
-                // mod.rs:119: no hit -> skybox(ray.direction) ends the chain
+            if (slot == 0xFFFFFFFFu || fp.max_depth == 0u) {
+                // mod.rs:119: no hit -> skybox(ray.direction) ends the chain; mod.rs:125-127: with max_depth == 0
+                // even a hit is shaded as skybox(ray.direction)
                 F3 c = skybox(fp, D);
                 io.term[0 * (size_t)cap + sample] = c.x;
                 io.term[1 * (size_t)cap + sample] = c.y;
