@@ -68,8 +68,9 @@ inline V2 add2(V2 a, V2 b) { return V2{a.x + b.x, a.y + b.y}; }
 inline V2 scale2(V2 a, float s) { return V2{a.x * s, a.y * s}; }
 
 // Rust f32::max / f32::min: if one operand is NaN the other is returned.
-inline float rmax(float a, float b) { return std::fmax(a, b); }
-inline float rmin(float a, float b) { return std::fmin(a, b); }
+// (written inline: without -ffinite-math-only gcc turns std::fmax into a libm call per box-test operand)
+inline float rmax(float a, float b) { return (a >= b || b != b) ? a : b; }
+inline float rmin(float a, float b) { return (a <= b || b != b) ? a : b; }
 
 // Column-major 4x4, element (r,c) at m[c*4+r] (nalgebra storage order).
 struct M4 {

@@ -92,6 +92,15 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc` "
                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7 / libhsa-runtime64, and a
+    # process that initialises /opt/rocm's copy first and torch's second ends up with two HSA runtimes (torch then
+    # reports "No HIP GPUs are available").  Importing torch first makes the dynamic loader bind this library's
+    # NEEDED libamdhip64.so.7 to the copy torch already loaded, so device pointers and streams can be shared.
+    if os.environ.get("TRR_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
     L.trr_version.restype = C.c_char_p

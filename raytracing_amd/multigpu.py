@@ -1,0 +1,114 @@
+"""Tile-sharded multi-GPU rendering: one process (rank) per GPU, scene replicated, the reference's own 20x20
+block grid (raytracer/render.rs:103-110) dealt round-robin to the ranks, ONE gather of the RGB8 strips.
+
+The reference has no multi-device path; its unit of parallel work is the block (render.rs:109-133, rayon
+``par_bridge`` over blocks).  Blocks are independent, so there is no data-path collective besides the final
+gather of finished pixels (RCCL over xGMI when the process group is ``nccl``).
+
+Host-side helpers (``tiling``, ``owned_blocks``, ``strip_from_frame``, ``assemble_host``) restate the block/strip
+layout of ``trr_render_shard_device`` / ``trr_assemble_device`` (include/trayracer_hip.h) in numpy for callers that
+hold strips in host memory and for the world_size-2 gloo tests.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+
+def tiling(width: int, height: int) -> Tuple[int, int, int, int]:
+    """(block_w, block_h, blocks_x, blocks_y) of render.rs:103-110; ZeroDivisionError below 20 px like render.rs:109."""
+    bw, bh = width // 20, height // 20
+    if bw == 0 or bh == 0:
+        raise ZeroDivisionError("resolution below 20 pixels: the reference divides by zero (render.rs:109)")
+    return bw, bh, width // bw, height // bh
+
+
+def owned_blocks(width: int, height: int, shard: int, n_shards: int) -> List[int]:
+    """Row-major block ids rendered by ``shard``: b % n_shards == shard."""
+    _, _, nbx, nby = tiling(width, height)
+    return list(range(shard, nbx * nby, n_shards))
+
+
+def strip_bytes(width: int, height: int, n_shards: int) -> int:
+    bw, bh, nbx, nby = tiling(width, height)
+    return ((nbx * nby + n_shards - 1) // n_shards) * bw * bh * 3
+
+
+def strip_from_frame(frame: np.ndarray, shard: int, n_shards: int) -> np.ndarray:
+    """Cuts the strip ``trr_render_shard_device`` would produce for ``shard`` out of a full frame [h, w, 3] u8."""
+    h, w = frame.shape[:2]
+    bw, bh, nbx, _ = tiling(w, h)
+    out = np.zeros(strip_bytes(w, h, n_shards), np.uint8)
+    for j, b in enumerate(owned_blocks(w, h, shard, n_shards)):
+        xb, yb = b % nbx, b // nbx
+        blk = frame[yb * bh:(yb + 1) * bh, xb * bw:(xb + 1) * bw]
+        out[j * bw * bh * 3:(j + 1) * bw * bh * 3] = blk.reshape(-1)
+    return out
+
+
+def assemble_host(strips: np.ndarray, width: int, height: int, n_shards: int) -> np.ndarray:
+    """``trr_assemble_device`` in numpy: n_shards contiguous strips -> row-major frame; the remainder strip
+    (render.rs:100-102) stays 0,0,0."""
+    bw, bh, nbx, nby = tiling(width, height)
+    sb = strip_bytes(width, height, n_shards)
+    strips = np.asarray(strips, np.uint8).reshape(n_shards, sb)
+    frame = np.zeros((height, width, 3), np.uint8)
+    for b in range(nbx * nby):
+        shard, j = b % n_shards, b // n_shards
+        xb, yb = b % nbx, b // nbx
+        blk = strips[shard, j * bw * bh * 3:(j + 1) * bw * bh * 3].reshape(bh, bw, 3)
+        frame[yb * bh:(yb + 1) * bh, xb * bw:(xb + 1) * bw] = blk
+    return frame
+
+
+def gather_strips_host(strip: np.ndarray, rank: int, world: int, group=None) -> Optional[np.ndarray]:
+    """One ``torch.distributed.gather`` of equal-size host strips to rank 0 (gloo).  Returns [world, strip_bytes] on
+    rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.from_numpy(np.ascontiguousarray(strip))
+    if world == 1:
+        return t.numpy().reshape(1, -1)
+    outs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, outs, dst=0, group=group)
+    return torch.stack(outs).numpy() if rank == 0 else None
+
+
+class ShardedRenderer:
+    """One rank of a tile-sharded render.  ``raytracer`` is this rank's ``Raytracer`` (scene already uploaded to this
+    rank's GPU).  ``render()`` queues shard render -> gather -> (root) assemble on torch's current stream and returns
+    the frame tensor [h, w, 3] u8 on the root's GPU (None on the other ranks); nothing is synchronised."""
+
+    def __init__(self, raytracer, rank: int = 0, world: int = 1, group=None):
+        import torch
+
+        self.rt = raytracer
+        self.rank, self.world, self.group = int(rank), int(world), group
+        self.device = torch.device("cuda", raytracer.ctx.device)
+        self.sb = raytracer.strip_bytes(self.world)
+        self.strip = torch.zeros(self.sb, dtype=torch.uint8, device=self.device)
+        self.is_root = self.rank == 0
+        if self.is_root:
+            self.strips = torch.zeros((self.world, self.sb), dtype=torch.uint8, device=self.device)
+            self.frame = torch.zeros((raytracer.height, raytracer.width, 3), dtype=torch.uint8, device=self.device)
+            self._views = [self.strips[i] for i in range(self.world)]
+
+    def render(self, stats=None, counters: bool = False):
+        import torch
+        import torch.distributed as dist
+
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.rt.render_shard_device(self.rank, self.world, self.strip.data_ptr(), self.sb, stream=stream, stats=stats,
+                                    counters=counters)
+        if self.world > 1:
+            # the single exchange of the path: finished RGB8 strips to the root (RCCL over xGMI with backend nccl)
+            dist.gather(self.strip, self._views if self.is_root else None, dst=0, group=self.group)
+            src = self.strips
+        else:
+            src = self.strip
+        if not self.is_root:
+            return None
+        self.rt.assemble_device(self.world, src.data_ptr(), self.frame.data_ptr(), stream=stream)
+        return self.frame

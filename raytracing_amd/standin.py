@@ -229,32 +229,90 @@ def _scale_counts(target, parts):
     return out
 
 
+TABLE_CENTER = (0.65, 1.84)   # object-space (x, z) under the centre of the config.yaml view
+TABLE_SCALE = 0.8
+
+
+def _place(s, d):
+    """Camera-aligned disc coordinates (s = screen-right, d = away from the camera, both through the disc centre)
+    -> object-space (x, z) for the res/test/config.yaml camera."""
+    return (0.925 * s - 0.379 * d, -0.379 * s - 0.925 * d)
+
+
 def car_object(n_tris=1_000_000, seed=1) -> Object:
-    """'Car-like' closed shell of displaced superellipsoids + torus wheels, ~n_tris triangles, mixed illum 2/3/4,
-    two materials without `d` (tinted shadows), one textured material."""
-    (bu, bv), (cu, cv), (wu, wv), (hu, hv) = _scale_counts(
-        n_tris, [(0.55, 2.0), (0.20, 2.0), (0.20, 4.0), (0.05, 2.0)])
-    wu = max(3, wu // 2)   # four wheels share the 20 %
+    """Stand-in for res/car_objs/car.obj (== res/test/car.obj, 87 MB): like the real file (see
+    res/test/render_example.png) ONE object holding a whole table-top arrangement -- a car shell with wheels, a
+    bin, a bust-like blob, a mirror sphere, a ring knot, an apple and a pencil -- ~n_tris triangles, mixed
+    illum 2/3/4, two materials without `d` (tinted shadows), two textured materials."""
+    w_car, w_bust, w_bin, w_sph, w_knot, w_apple, w_pen = 0.40, 0.15, 0.08, 0.08, 0.12, 0.12, 0.05
+    ((bu, bv), (cu, cv), (wu, wv), (hu, hv), (su, sv), (nu_, nv_), (pu, pv), (ku, kv), (au, av), (eu, ev)) = _scale_counts(
+        n_tris, [(w_car * 0.55, 2.0), (w_car * 0.20, 2.0), (w_car * 0.20, 4.0), (w_car * 0.05, 2.0),
+                 (w_bust, 2.0), (w_bin, 3.0), (w_sph, 2.0), (w_knot, 5.0), (w_apple, 2.0), (w_pen, 0.25)])
+    wu = max(3, wu // 2)   # four wheels share their budget
     wv = max(3, wv // 2)
     parts, mats_idx = [], []
-    body = superellipsoid(bu, bv, (1.05, 0.42, 2.3), e1=0.55, e2=0.7, center=(0.0, 0.62, 0.0), bump=0.05, seed=seed)
-    parts.append(body); mats_idx.append(np.where(np.arange(len(body)) % 7 == 0, 1, 0))
-    cabin = superellipsoid(cu, cv, (0.82, 0.38, 1.15), e1=0.8, e2=0.8, center=(0.0, 1.12, -0.25), bump=0.02, seed=seed + 7)
-    parts.append(cabin); mats_idx.append(np.full(len(cabin), 2))
-    for k, (sx, sz) in enumerate([(-1.0, 1.45), (1.0, 1.45), (-1.0, -1.45), (1.0, -1.45)]):
-        wh = torus(wu, wv, 0.33, 0.13, center=(sx * 0.98, 0.46, sz), axis=0)
-        parts.append(wh); mats_idx.append(np.full(len(wh), 3))
-    for k, sx in enumerate((-0.55, 0.55)):
-        hl = superellipsoid(max(3, hu // 2), max(2, hv // 2), (0.22, 0.13, 0.08), center=(sx, 0.68, 2.28))
-        parts.append(hl); mats_idx.append(np.full(len(hl), 4))
+
+    def add(tri, mat):
+        parts.append(tri)
+        mats_idx.append(np.full(len(tri), mat) if np.isscalar(mat) else mat)
+
+    cx, cz = _place(-3.4, -1.2)
+    body = superellipsoid(bu, bv, (1.05, 0.42, 2.3), e1=0.55, e2=0.7, center=(cx, 0.62, cz), bump=0.05, seed=seed)
+    add(body, np.where(np.arange(len(body)) % 7 == 0, 1, 0))
+    add(superellipsoid(cu, cv, (0.82, 0.38, 1.15), e1=0.8, e2=0.8, center=(cx, 1.12, cz - 0.25), bump=0.02, seed=seed + 7), 2)
+    for sx, sz in [(-1.0, 1.45), (1.0, 1.45), (-1.0, -1.45), (1.0, -1.45)]:
+        add(torus(wu, wv, 0.33, 0.13, center=(cx + sx * 0.98, 0.46, cz + sz), axis=0), 3)
+    for sx in (-0.55, 0.55):
+        add(superellipsoid(max(3, hu // 2), max(2, hv // 2), (0.22, 0.13, 0.08), center=(cx + sx, 0.68, cz + 2.28)), 4)
+    x, z = _place(0.0, 2.6)     # bust: bumpy head on a narrower neck
+    add(superellipsoid(su, sv, (0.55, 0.75, 0.6), e1=0.9, e2=0.9, center=(x, 1.75, z), bump=0.22, seed=seed + 11, bump_freq=9.0), 5)
+    add(superellipsoid(max(3, su // 2), max(2, sv // 2), (0.62, 0.5, 0.5), e1=0.6, e2=0.9, center=(x, 0.5, z), bump=0.1, seed=seed + 12), 5)
+    x, z = _place(-1.7, 2.4)     # bin: squarish barrel, rust texture
+    add(superellipsoid(nu_, nv_, (0.6, 1.15, 0.6), e1=0.25, e2=0.9, center=(x, 1.15, z), bump=0.03, seed=seed + 13), 6)
+    x, z = _place(2.0, 2.9)      # mirror sphere
+    add(superellipsoid(pu, pv, (1.0, 1.0, 1.0), center=(x, 1.0, z)), 7)
+    x, z = _place(4.3, 1.8)      # knot: two interlocked rings
+    add(torus(ku, max(3, kv // 2), 0.75, 0.24, center=(x, 0.55, z), axis=1), 8)
+    add(torus(ku, max(3, kv // 2), 0.75, 0.24, center=(x + 0.55, 0.85, z), axis=2), 8)
+    x, z = _place(3.1, -2.2)     # apple
+    add(superellipsoid(au, av, (1.15, 1.05, 1.15), e1=0.85, e2=1.0, center=(x, 1.05, z), bump=0.06, seed=seed + 17, bump_freq=3.0), 9)
+    x, z = _place(0.3, -1.8)     # pencil along screen-right
+    pen = superellipsoid(eu, ev, (1.9, 0.07, 0.07), e1=0.3, e2=1.0, center=(0.0, 0.0, 0.0))
+    ang = np.arctan2(-0.379, 0.925) + 0.12   # direction of screen-right in the xz plane, slightly skewed
+    ca, sa = np.cos(ang), np.sin(ang)
+    pen64 = pen.astype(np.float64)
+    for k in (0, 3, 6, 9, 12, 15):   # rotate positions and normals about +Y, then translate the positions
+        px, pz = pen64[:, k].copy(), pen64[:, k + 2].copy()
+        pen64[:, k] = ca * px - sa * pz
+        pen64[:, k + 2] = sa * px + ca * pz
+    for k in (0, 3, 6):
+        pen64[:, k] += x
+        pen64[:, k + 1] += 0.09
+        pen64[:, k + 2] += z
+    add(np.ascontiguousarray(pen64.astype(F32)), 10)
     tri = np.concatenate(parts, axis=0)
+    # shrink the arrangement about the point where the config.yaml camera's axis meets the floor
+    tri64 = tri.astype(np.float64)
+    for k in (0, 3, 6):
+        tri64[:, k] = TABLE_CENTER[0] + TABLE_SCALE * tri64[:, k]
+        tri64[:, k + 1] = TABLE_SCALE * tri64[:, k + 1]
+        tri64[:, k + 2] = TABLE_CENTER[1] + TABLE_SCALE * tri64[:, k + 2]
+    tri = np.ascontiguousarray(tri64.astype(F32))
     mi = np.concatenate(mats_idx).astype(np.int32)
+    rust = checker_texture(388, 284, 24, (120, 70, 40), (80, 45, 30))      # size of res/test/textures' 388x284 image
+    skin = checker_texture(1024, 1024, 64, (235, 120, 40), (220, 60, 30))  # size of the two 1024^2 JPGs
     mats = [
         _mat("paint", kd=(0.03, 0.22, 0.06), ks=(0.5, 0.5, 0.5), ns=180.0, illum=3, d=1.0),
         _mat("paint_stripe", kd=(0.3, 0.28, 0.26), ks=(0.3, 0.3, 0.3), ns=60.0, illum=2, d=1.0),
         _mat("glass", kd=(0.03, 0.04, 0.05), ks=(1.0, 1.0, 1.0), ns=400.0, illum=4),          # no d -> dissolve None
         _mat("rubber", kd=(0.02, 0.02, 0.02), ks=(0.1, 0.1, 0.1), ns=12.0, illum=2, d=1.0),
         _mat("chrome", kd=(0.18, 0.18, 0.18), ks=(1.0, 1.0, 1.0), ns=800.0, illum=3),           # no d
+        _mat("marble", kd=(0.75, 0.68, 0.6), ks=(0.2, 0.2, 0.2), ns=30.0, illum=2, d=1.0),
+        _mat("rust", kd=(0.4, 0.25, 0.15), ks=(0.1, 0.1, 0.1), ns=8.0, illum=2, d=1.0, tex=rust),
+        _mat("mirror", kd=(0.02, 0.02, 0.02), ks=(1.0, 1.0, 1.0), ns=900.0, illum=3, d=1.0),
+        _mat("pink", kd=(0.8, 0.25, 0.55), ks=(0.4, 0.4, 0.4), ns=50.0, illum=2, d=1.0),
+        _mat("apple", kd=(0.8, 0.3, 0.1), ks=(0.3, 0.3, 0.3), ns=70.0, illum=2, d=1.0, tex=skin),
+        _mat("pencil", kd=(0.08, 0.06, 0.25), ks=(0.5, 0.5, 0.5), ns=100.0, illum=2, d=1.0),
     ]
     return Object(name="Car", triangles=tri, material_index=mi, materials=mats,
                   translation=np.array(CONFIG_YAML_TRANSLATION, F32))
@@ -263,7 +321,7 @@ def car_object(n_tris=1_000_000, seed=1) -> Object:
 def floor_object(n_tris=300_000) -> Object:
     nr = max(2, int(round((n_tris / 8.0) ** 0.5)))
     nt = max(3, int(round(n_tris / (2.0 * nr))))
-    tri = disc(nr, nt, 9.0, y=0.0)
+    tri = disc(nr, nt, 4.8, y=0.0, center=TABLE_CENTER)
     mats = [_mat("floor", kd=(0.035, 0.045, 0.04), ks=(0.6, 0.6, 0.6), ns=90.0, illum=3, d=1.0)]
     return Object(name="Floor", triangles=tri, material_index=np.zeros(len(tri), np.int32), materials=mats,
                   translation=np.array(CONFIG_YAML_TRANSLATION, F32))

@@ -1,5 +1,9 @@
 """Shared helpers of the parity tests."""
+import json
+
 import numpy as np
+
+from raytracing_amd.scene import Camera, IlluminationModel, Light, Material, Object, Scene, Settings, Skybox
 
 
 def compare_images(gpu_rgb, ref_rgb):
@@ -11,3 +15,78 @@ def compare_images(gpu_rgb, ref_rgb):
 def compare_ids(g_obj, g_tri, r_obj, r_tri):
     same = (g_obj == r_obj) & (g_tri == r_tri)
     return float(same.mean())
+
+
+# The bar of BASELINE.json's north_star (fractions of pixels).
+ID_BAR = 0.9999
+RGB_BAR = 0.999
+
+
+def assert_parity(out, ref, ids=True, what=""):
+    if ids:
+        f = compare_ids(out["hit_obj"], out["hit_tri"], ref["hit_obj"], ref["hit_tri"])
+        assert f >= ID_BAR, f"{what}: primary-hit ids identical on only {f:.6f} of pixels"
+    w1, ex, mx = compare_images(out["rgb"], ref["rgb"])
+    assert w1 >= RGB_BAR, f"{what}: RGB8 within 1 LSB on only {w1:.6f} of pixels (exact {ex:.6f}, max diff {mx})"
+    return w1, ex
+
+
+# ---- hermetic scene (de)serialisation for tests/golden: geometry generated with numpy's float64 transcendental
+# loops may differ in the last bit between CPUs, so fixtures carry their inputs with them -------------------------
+def scene_to_arrays(sc: Scene) -> dict:
+    d = {}
+    meta = {"n_objects": len(sc.objects), "objects": [], "lights": [], "settings": {}, "camera": {}}
+    for i, o in enumerate(sc.objects):
+        d[f"o{i}_tri"] = o.triangles
+        d[f"o{i}_mi"] = o.material_index
+        mats = []
+        for k, m in enumerate(o.materials):
+            mats.append({
+                "name": m.name,
+                "kd": None if m.diffuse_color is None else [float(x) for x in m.diffuse_color],
+                "ks": None if m.specular_color is None else [float(x) for x in m.specular_color],
+                "ns": m.specular_exponent, "illum": m.illumination_model.value, "dissolve": m.dissolve,
+                "tex": m.diffuse_texture is not None})
+            if m.diffuse_texture is not None:
+                d[f"o{i}_m{k}_tex"] = m.diffuse_texture
+        meta["objects"].append({"name": o.name, "materials": mats})
+        d[f"o{i}_trs"] = np.concatenate([o.translation, o.rotation, o.scale]).astype(np.float32)
+    d["lights"] = np.array([[*l.position, *l.color, l.intensity] for l in sc.lights], np.float32).reshape(-1, 7)
+    s = sc.settings
+    d["ambient"] = np.array([*s.ambient_color, s.ambient_intensity], np.float32)
+    meta["settings"] = {"samples": s.samples, "aa": bool(s.anti_aliasing), "seed": int(s.seed), "sky_image": s.skybox.image is not None}
+    if s.skybox.image is not None:
+        d["sky"] = s.skybox.image
+    else:
+        d["sky_color"] = np.asarray(s.skybox.color, np.float32)
+    c = sc.camera
+    d["camera"] = np.array([*c.position, *c.look_at, *c.up, c.fov], np.float32)
+    meta["camera"] = {"resolution": [int(c.resolution[0]), int(c.resolution[1])]}
+    d["meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
+    return d
+
+
+def scene_from_arrays(d) -> Scene:
+    meta = json.loads(bytes(d["meta"]).decode())
+    objs = []
+    for i, om in enumerate(meta["objects"]):
+        mats = []
+        for k, m in enumerate(om["materials"]):
+            mats.append(Material(
+                name=m["name"], diffuse_color=None if m["kd"] is None else np.array(m["kd"], np.float32),
+                specular_color=None if m["ks"] is None else np.array(m["ks"], np.float32), specular_exponent=m["ns"],
+                diffuse_texture=np.ascontiguousarray(d[f"o{i}_m{k}_tex"]) if m["tex"] else None,
+                illumination_model=IlluminationModel(m["illum"]), dissolve=m["dissolve"]))
+        trs = d[f"o{i}_trs"]
+        objs.append(Object(name=om["name"], triangles=d[f"o{i}_tri"], material_index=d[f"o{i}_mi"], materials=mats,
+                           translation=trs[0:3], rotation=trs[3:7], scale=trs[7:10]))
+    lights = [Light(np.array(r[0:3], np.float32), np.array(r[3:6], np.float32), float(r[6])) for r in d["lights"]]
+    sm = meta["settings"]
+    sky = Skybox(image=np.ascontiguousarray(d["sky"])) if sm["sky_image"] else Skybox(color=np.array(d["sky_color"], np.float32))
+    amb = d["ambient"]
+    st = Settings(samples=sm["samples"], ambient_color=np.array(amb[0:3], np.float32), ambient_intensity=float(amb[3]),
+                  skybox=sky, anti_aliasing=sm["aa"], seed=sm["seed"])
+    cam = d["camera"]
+    c = Camera(position=np.array(cam[0:3], np.float32), look_at=np.array(cam[3:6], np.float32), up=np.array(cam[6:9], np.float32),
+               fov=float(cam[9]), resolution=tuple(meta["camera"]["resolution"]))
+    return Scene(objects=objs, lights=lights, camera=c, settings=st)
