@@ -116,6 +116,12 @@ typedef struct trr_stats {
     double ms_shade;               /* HIP-event time of the hit-setup + resolve launches */
     uint32_t trace_launches;
     uint32_t blocks_rendered;
+    /* SIMD-efficiency diagnostics of the trace kernel, filled only with TRR_FLAG_COUNTERS: steps counted once per
+     * WAVEFRONT (a step runs for all 64 lanes whether 1 or 64 of them need it) */
+    uint64_t wave_node_steps;      /* inner-node iterations; node_visits / (64 * this) = lane utilisation */
+    uint64_t wave_tri_steps;       /* triangle-slot iterations of the leaf loop; box_tests-4*node_visits over 64*this */
+    uint64_t wave_outer_steps;     /* outer (refill / transition / descend / leaf) iterations */
+    uint64_t wave_lane_steps;      /* sum over outer iterations of lanes that still carry a ray */
 } trr_stats;
 
 typedef void (*trr_progress_cb)(void* user, uint32_t blocks_done, uint32_t blocks_total);

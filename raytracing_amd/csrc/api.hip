@@ -731,6 +731,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
                 stats->rays_reflection += w[CW_NCHAIN + lvl + 1];
             }
             stats->node_visits += k[0]; stats->box_tests += k[1]; stats->tri_tests += k[2]; stats->rays_march += k[3];
+            stats->wave_node_steps += k[4]; stats->wave_tri_steps += k[5]; stats->wave_outer_steps += k[6]; stats->wave_lane_steps += k[7];
         }
         for (size_t i = 0; i + 1 < n_events; i += 2) {
             float ms = 0.0f;

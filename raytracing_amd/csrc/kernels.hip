@@ -172,6 +172,10 @@ constexpr int REFILL_MIN = TRR_REFILL_MIN;      // re-fill when at least this ma
 #define TRR_PRUNE_REL 1.0e-3f
 #endif
 constexpr float PRUNE_REL = TRR_PRUNE_REL;
+#ifndef TRR_NODE_BIAS
+#define TRR_NODE_BIAS 8
+#endif
+constexpr int NODE_BIAS = TRR_NODE_BIAS;   // a node step runs when 8ths-weighted inner lanes >= leaf lanes
 
 
 // triangle.rs:53-85 + object.rs:201,206 for one 64-B TriRec (normal and |ab x ac| precomputed with the same
@@ -244,6 +248,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchPa
     uint32_t cur = REF_EMPTY;
     int sp = 0;
     unsigned long long c_nodes = 0, c_boxes = 0, c_tris = 0, c_march = 0;
+    unsigned long long c_wnode = 0, c_wtri = 0, c_wouter = 0, c_lanes = 0;   // wave-level step counts (SIMD efficiency)
 
     auto push = [&](uint32_t ref, float tmin) {
         uint2 e = make_uint2(ref, __float_as_uint(tmin));
@@ -304,6 +309,10 @@ __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchPa
             }
         }
         if (__ballot(active) == 0ull) break;
+        if (COUNT) {
+            if (lane == 0) c_wouter++;
+            if (active) c_lanes++;
+        }
 
         // ---- transition: object finished / raycast finished / ray finished ----------------------
         if (active && cur == REF_EMPTY) {
@@ -402,52 +411,66 @@ __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchPa
             }
         }
 
-        // ---- inner nodes: descend until a leaf (or nothing) is current ---------------------------
-        while (active && cur < REF_LEAF) {
-            const float4* nd = reinterpret_cast<const float4*>(fp.nodes + cur);
-            float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
-            uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
-            if (COUNT) { c_nodes++; c_boxes += 4; }
-            float tm[4];
-            uint32_t rf[4] = {ch.x, ch.y, ch.z, ch.w};
-            const float lxs[4] = {lox.x, lox.y, lox.z, lox.w}, lys[4] = {loy.x, loy.y, loy.z, loy.w},
-                        lzs[4] = {loz.x, loz.y, loz.z, loz.w}, hxs[4] = {hix.x, hix.y, hix.z, hix.w},
-                        hys[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hzs[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+        // ---- one step per iteration, chosen for the WHOLE wavefront: either every lane that stands on an inner node
+        // visits it, or every lane that stands on a leaf tests ONE of its triangles.  The kind with more waiting lanes
+        // runs (node steps weighted by NODE_BIAS/8); the other lanes keep their state for a later iteration.  A step
+        // costs the same whether 1 or 64 lanes need it, so this keeps the SIMD lanes of divergent rays busy.
+        const unsigned long long m_inner = __ballot(active && cur < REF_LEAF);
+        const unsigned long long m_leaf = __ballot(active && cur >= REF_LEAF && cur != REF_EMPTY);
+        const bool node_step = m_inner != 0ull && (__popcll(m_inner) * NODE_BIAS >= __popcll(m_leaf) * 8);
+
+        if (node_step) {
+            if (active && cur < REF_LEAF) {
+                const float4* nd = reinterpret_cast<const float4*>(fp.nodes + cur);
+                float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
+                uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
+                if (COUNT) {
+                    c_nodes++; c_boxes += 4;
+                    if (lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) c_wnode++;
+                }
+                float tm[4];
+                uint32_t rf[4] = {ch.x, ch.y, ch.z, ch.w};
+                const float lxs[4] = {lox.x, lox.y, lox.z, lox.w}, lys[4] = {loy.x, loy.y, loy.z, loy.w},
+                            lzs[4] = {loz.x, loz.y, loz.z, loz.w}, hxs[4] = {hix.x, hix.y, hix.z, hix.w},
+                            hys[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hzs[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                // [crate] Ray::intersects_aabb, same arithmetic as the per-triangle test below, so a parent box
-                // (exact union of its children) can never reject what a triangle's own box accepts
-                float ax = (lxs[k] - oo.x) * oi.x, bx = (hxs[k] - oo.x) * oi.x;
-                float ay = (lys[k] - oo.y) * oi.y, by = (hys[k] - oo.y) * oi.y;
-                float az = (lzs[k] - oo.z) * oi.z, bz = (hzs[k] - oo.z) * oi.z;
-                float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));
-                float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));
-                bool hit = (rf[k] != REF_EMPTY) && (tmax > rmax(tmin, 0.0f)) && !(tmin > lim_n);
-                tm[k] = hit ? tmin : INFINITY;
-                if (!hit) rf[k] = REF_EMPTY;
-                if (hit && is_nan(tmin)) tm[k] = -INFINITY;   // keep NaN-boxed children (and visit them first)
-            }
-            // sort the four (tmin, ref) pairs ascending: 5-comparator network
+                for (int k = 0; k < 4; ++k) {
+                    // [crate] Ray::intersects_aabb, same arithmetic as the per-triangle test below, so a parent box
+                    // (exact union of its children) can never reject what a triangle's own box accepts
+                    float ax = (lxs[k] - oo.x) * oi.x, bx = (hxs[k] - oo.x) * oi.x;
+                    float ay = (lys[k] - oo.y) * oi.y, by = (hys[k] - oo.y) * oi.y;
+                    float az = (lzs[k] - oo.z) * oi.z, bz = (hzs[k] - oo.z) * oi.z;
+                    float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));
+                    float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));
+                    bool hit = (rf[k] != REF_EMPTY) && (tmax > rmax(tmin, 0.0f)) && !(tmin > lim_n);
+                    tm[k] = hit ? tmin : INFINITY;
+                    if (!hit) rf[k] = REF_EMPTY;
+                    if (hit && is_nan(tmin)) tm[k] = -INFINITY;   // keep NaN-boxed children (and visit them first)
+                }
+                // sort the four (tmin, ref) pairs ascending: 5-comparator network
 #define TRR_CSWAP(i, j)                                                        \
     if (tm[j] < tm[i]) {                                                       \
         float tt_ = tm[i]; tm[i] = tm[j]; tm[j] = tt_;                         \
         uint32_t rr_ = rf[i]; rf[i] = rf[j]; rf[j] = rr_;                      \
     }
-            TRR_CSWAP(0, 1) TRR_CSWAP(2, 3) TRR_CSWAP(0, 2) TRR_CSWAP(1, 3) TRR_CSWAP(1, 2)
+                TRR_CSWAP(0, 1) TRR_CSWAP(2, 3) TRR_CSWAP(0, 2) TRR_CSWAP(1, 3) TRR_CSWAP(1, 2)
 #undef TRR_CSWAP
-            if (rf[3] != REF_EMPTY) push(rf[3], tm[3]);
-            if (rf[2] != REF_EMPTY) push(rf[2], tm[2]);
-            if (rf[1] != REF_EMPTY) push(rf[1], tm[1]);
-            cur = (rf[0] != REF_EMPTY) ? rf[0] : pop();
-        }
-
-        // ---- leaf: own-box test + exact test on up to 4 triangles --------------------------------
-        if (active && cur != REF_EMPTY) {
-            uint32_t first = (cur & 0x7FFFFFFFu) >> 2, cnt = (cur & 3u) + 1u;
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const float4* tp = reinterpret_cast<const float4*>(fp.tris + first + j);
+                if (rf[3] != REF_EMPTY) push(rf[3], tm[3]);
+                if (rf[2] != REF_EMPTY) push(rf[2], tm[2]);
+                if (rf[1] != REF_EMPTY) push(rf[1], tm[1]);
+                cur = (rf[0] != REF_EMPTY) ? rf[0] : pop();
+            }
+        } else if (m_leaf != 0ull) {
+            // ---- leaf: own-box test + exact test of the leaf's first remaining triangle ------------------------
+            if (active && cur >= REF_LEAF && cur != REF_EMPTY) {
+                const uint32_t slot = (cur & 0x7FFFFFFFu) >> 2;
+                const float4* tp = reinterpret_cast<const float4*>(fp.tris + slot);
                 float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
-                if (COUNT) c_boxes++;
+                if (COUNT) {
+                    c_boxes++;
+                    if (lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) c_wtri++;
+                }
+                bool cand = true;
                 if (!skipbox) {
                     // triangle.rs:88-95 box (empty.grow(a).grow(b).grow(c + 1e-4)) + [crate] slab test
                     F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x);
@@ -459,20 +482,24 @@ __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchPa
                     float az = (lo.z - oo.z) * oi.z, bz = (hi.z - oo.z) * oi.z;
                     float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));
                     float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));
-                    if (!(tmax > rmax(tmin, 0.0f))) continue;
-                    if (tmin > lim_n) continue;   // cannot beat the current best (slack keeps this conservative)
+                    // the second condition: cannot beat the current best (slack keeps this conservative)
+                    cand = (tmax > rmax(tmin, 0.0f)) && !(tmin > lim_n);
                 }
-                if (COUNT) c_tris++;
-                TriHit h;
-                if (!tri_test(q0, q1, q2, q3.z, oo, od, fp.delta, h)) continue;
-                uint32_t tri_id = __float_as_uint(q3.x);
-                if (candidate_better(o_have, h.key, tri_id, o_key, o_tri)) {
-                    o_have = true; o_key = h.key; o_slot = first + j; o_tri = tri_id;
-                    float dist = sqrtf(h.key);
-                    if (dist == dist) lim_n = rmin(lim_n, dist * (1.0f + PRUNE_REL) + slack_abs);
+                if (cand) {
+                    if (COUNT) c_tris++;
+                    TriHit h;
+                    if (tri_test(q0, q1, q2, q3.z, oo, od, fp.delta, h)) {
+                        uint32_t tri_id = __float_as_uint(q3.x);
+                        if (candidate_better(o_have, h.key, tri_id, o_key, o_tri)) {
+                            o_have = true; o_key = h.key; o_slot = slot; o_tri = tri_id;
+                            float dist = sqrtf(h.key);
+                            if (dist == dist) lim_n = rmin(lim_n, dist * (1.0f + PRUNE_REL) + slack_abs);
+                        }
+                    }
                 }
+                // next triangle of the leaf (ref = LEAF | first << 2 | count-1  ->  first+1, count-2), else pop
+                cur = (cur & 3u) ? cur + 3u : pop();
             }
-            cur = pop();
         }
     }
 
@@ -483,12 +510,20 @@ __global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchPa
             c_boxes += __shfl_down(c_boxes, off);
             c_tris += __shfl_down(c_tris, off);
             c_march += __shfl_down(c_march, off);
+            c_wnode += __shfl_down(c_wnode, off);
+            c_wtri += __shfl_down(c_wtri, off);
+            c_wouter += __shfl_down(c_wouter, off);
+            c_lanes += __shfl_down(c_lanes, off);
         }
         if (lane == 0) {
             atomicAdd(io.counters + 0, c_nodes);
             atomicAdd(io.counters + 1, c_boxes);
             atomicAdd(io.counters + 2, c_tris);
             atomicAdd(io.counters + 3, c_march);
+            atomicAdd(io.counters + 4, c_wnode);
+            atomicAdd(io.counters + 5, c_wtri);
+            atomicAdd(io.counters + 6, c_wouter);
+            atomicAdd(io.counters + 7, c_lanes);
         }
     }
 }
