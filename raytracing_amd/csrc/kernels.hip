@@ -162,8 +162,14 @@ DEV F3 primary_dir(const FrameParams& fp, uint32_t x, uint32_t y, uint32_t si) {
 // has finished are re-filled (ballot + one atomic per wavefront) once enough of them are idle.
 // ------------------------------------------------------------------------------------------------
 constexpr int TRACE_THREADS = 256;
-constexpr int STACK_LDS = 16;       // per-lane (ref, tmin) entries kept in LDS
-constexpr int STACK_SPILL = 48;     // further entries in a per-thread HBM spill area (rarely touched)
+#ifndef TRR_WAVES_PER_EU
+#define TRR_WAVES_PER_EU 6
+#endif
+#ifndef TRR_STACK_LDS
+#define TRR_STACK_LDS 16
+#endif
+constexpr int STACK_LDS = TRR_STACK_LDS;       // per-lane (ref, tmin) entries kept in LDS
+constexpr int STACK_SPILL = 64 - STACK_LDS;     // further entries in a per-thread HBM spill area (rarely touched)
 #ifndef TRR_REFILL_MIN
 #define TRR_REFILL_MIN 20
 #endif
@@ -215,7 +221,7 @@ DEV bool candidate_better(bool have, float key, uint32_t tri, float best_key, ui
 }
 
 template <bool RAYGEN, bool COUNT>
-__global__ void __launch_bounds__(TRACE_THREADS) k_trace(FrameParams fp, BatchParams bp, TraceIO io) {
+__global__ void __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(TRR_WAVES_PER_EU, 8))) k_trace(FrameParams fp, BatchParams bp, TraceIO io) {
     __shared__ uint2 s_stack[STACK_LDS * TRACE_THREADS];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
