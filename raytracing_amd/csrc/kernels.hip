@@ -162,8 +162,10 @@ DEV F3 primary_dir(const FrameParams& fp, uint32_t x, uint32_t y, uint32_t si) {
 // has finished are re-filled (ballot + one atomic per wavefront) once enough of them are idle.
 // ------------------------------------------------------------------------------------------------
 constexpr int TRACE_THREADS = 256;
-#ifndef TRR_WAVES_PER_EU
-#define TRR_WAVES_PER_EU 6
+#ifdef TRR_WAVES_PER_EU
+#define TRR_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(TRR_WAVES_PER_EU, 8)))
+#else
+#define TRR_OCCUPANCY_ATTR
 #endif
 #ifndef TRR_STACK_LDS
 #define TRR_STACK_LDS 16
@@ -221,7 +223,7 @@ DEV bool candidate_better(bool have, float key, uint32_t tri, float best_key, ui
 }
 
 template <bool RAYGEN, bool COUNT>
-__global__ void __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per_eu(TRR_WAVES_PER_EU, 8))) k_trace(FrameParams fp, BatchParams bp, TraceIO io) {
+__global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(FrameParams fp, BatchParams bp, TraceIO io) {
     __shared__ uint2 s_stack[STACK_LDS * TRACE_THREADS];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -236,7 +238,10 @@ __global__ void __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per
 
     // ---- per-lane state (results go to memory as soon as a raycast ends; only the winner's slot/key stay live) ----
     bool active = false;
-    bool exhausted = false;
+    bool exhausted = false, last_chunk = false;          // wave-uniform
+    uint32_t w_next = 0, w_end = 0;                      // wave-uniform: this wavefront's claimed range of work items
+    // chunk: ~1/8 of a wavefront's fair share, between one wavefront's worth and 512 items
+    const uint32_t chunk = max(64u, min(512u, total / (gridDim.x * (TRACE_THREADS / 64) * 8u)));
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 0);      // world ray (origin advances during the march)
     uint32_t r_out = 0, r_sample = 0, r_meta = 0;
     bool first_cast = true;                      // no raycast of this ray has finished yet
@@ -278,12 +283,22 @@ __global__ void __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per
         if (idle != 0ull && !exhausted) {
             int nidle = __popcll(idle);
             if (nidle >= REFILL_MIN) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(io.work_counter, (uint32_t)nidle);
-                base = __shfl(base, 0);
+                // work is claimed from the device counter in chunks per wavefront (one same-address atomic per chunk,
+                // not per re-fill: 10^6s of atomics on one word serialise in L2) and dealt to idle lanes from the chunk
+                if (w_next >= w_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(io.work_counter, chunk);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    w_next = min(base, total);
+                    w_end = min(base + chunk, total);
+                    if (base + chunk >= total) last_chunk = true;
+                }
+                const uint32_t take = min((uint32_t)nidle, w_end - w_next);
                 uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                uint32_t idx = base + rank;
-                if (!active && idx < total) {
+                uint32_t idx = w_next + rank;
+                w_next += take;
+                if (last_chunk && w_next >= w_end) exhausted = true;
+                if (!active && rank < take) {
                     if (RAYGEN) {
                         uint32_t pix = idx / fp.spp, si = idx - pix * fp.spp;
                         PixelPos pp = pixel_of(fp, bp, pix);
@@ -311,7 +326,6 @@ __global__ void __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per
                     cur = REF_EMPTY;
                     sp = 0;
                 }
-                if (base + (uint32_t)nidle >= total) exhausted = true;
             }
         }
         if (__ballot(active) == 0ull) break;
@@ -434,37 +448,44 @@ __global__ void __launch_bounds__(TRACE_THREADS) __attribute__((amdgpu_waves_per
                     c_nodes++; c_boxes += 4;
                     if (lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) c_wnode++;
                 }
-                float tm[4];
-                uint32_t rf[4] = {ch.x, ch.y, ch.z, ch.w};
-                const float lxs[4] = {lox.x, lox.y, lox.z, lox.w}, lys[4] = {loy.x, loy.y, loy.z, loy.w},
-                            lzs[4] = {loz.x, loz.y, loz.z, loz.w}, hxs[4] = {hix.x, hix.y, hix.z, hix.w},
-                            hys[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hzs[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // [crate] Ray::intersects_aabb, same arithmetic as the per-triangle test below, so a parent box
-                    // (exact union of its children) can never reject what a triangle's own box accepts
-                    float ax = (lxs[k] - oo.x) * oi.x, bx = (hxs[k] - oo.x) * oi.x;
-                    float ay = (lys[k] - oo.y) * oi.y, by = (hys[k] - oo.y) * oi.y;
-                    float az = (lzs[k] - oo.z) * oi.z, bz = (hzs[k] - oo.z) * oi.z;
-                    float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));
-                    float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));
-                    bool hit = (rf[k] != REF_EMPTY) && (tmax > rmax(tmin, 0.0f)) && !(tmin > lim_n);
-                    tm[k] = hit ? tmin : INFINITY;
-                    if (!hit) rf[k] = REF_EMPTY;
-                    if (hit && is_nan(tmin)) tm[k] = -INFINITY;   // keep NaN-boxed children (and visit them first)
-                }
-                // sort the four (tmin, ref) pairs ascending: 5-comparator network
-#define TRR_CSWAP(i, j)                                                        \
-    if (tm[j] < tm[i]) {                                                       \
-        float tt_ = tm[i]; tm[i] = tm[j]; tm[j] = tt_;                         \
-        uint32_t rr_ = rf[i]; rf[i] = rf[j]; rf[j] = rr_;                      \
+                // [crate] Ray::intersects_aabb per child, same arithmetic as the per-triangle test below, so a parent
+                // box (exact union of its children) can never reject what a triangle's own box accepts.  Written with
+                // scalars and selects only (no arrays, no short-circuit branches): keeps the step branch-free.
+                // A NaN tmin keeps the child (and sorts it first).
+#define TRR_BOX(T, R, LX, LY, LZ, HX, HY, HZ, CH)                                                          \
+    float T;                                                                                               \
+    uint32_t R;                                                                                            \
+    {                                                                                                      \
+        float ax = ((LX) - oo.x) * oi.x, bx = ((HX) - oo.x) * oi.x;                                        \
+        float ay = ((LY) - oo.y) * oi.y, by = ((HY) - oo.y) * oi.y;                                        \
+        float az = ((LZ) - oo.z) * oi.z, bz = ((HZ) - oo.z) * oi.z;                                        \
+        float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));                                 \
+        float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));                                 \
+        bool hit = ((CH) != REF_EMPTY) & (tmax > rmax(tmin, 0.0f)) & !(tmin > lim_n);                      \
+        float key = is_nan(tmin) ? -INFINITY : tmin;                                                       \
+        T = hit ? key : INFINITY;                                                                          \
+        R = hit ? (CH) : REF_EMPTY;                                                                        \
     }
-                TRR_CSWAP(0, 1) TRR_CSWAP(2, 3) TRR_CSWAP(0, 2) TRR_CSWAP(1, 3) TRR_CSWAP(1, 2)
+                TRR_BOX(t0, r0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x)
+                TRR_BOX(t1, r1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y)
+                TRR_BOX(t2, r2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
+                TRR_BOX(t3, r3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
+#undef TRR_BOX
+                // sort the four (tmin, ref) pairs ascending: 5-comparator network of selects
+#define TRR_CSWAP(TI, RI, TJ, RJ)                                                  \
+    {                                                                              \
+        bool sw_ = TJ < TI;                                                        \
+        float ta_ = sw_ ? TJ : TI, tb_ = sw_ ? TI : TJ;                            \
+        uint32_t ra_ = sw_ ? RJ : RI, rb_ = sw_ ? RI : RJ;                         \
+        TI = ta_; TJ = tb_; RI = ra_; RJ = rb_;                                    \
+    }
+                TRR_CSWAP(t0, r0, t1, r1) TRR_CSWAP(t2, r2, t3, r3) TRR_CSWAP(t0, r0, t2, r2)
+                TRR_CSWAP(t1, r1, t3, r3) TRR_CSWAP(t1, r1, t2, r2)
 #undef TRR_CSWAP
-                if (rf[3] != REF_EMPTY) push(rf[3], tm[3]);
-                if (rf[2] != REF_EMPTY) push(rf[2], tm[2]);
-                if (rf[1] != REF_EMPTY) push(rf[1], tm[1]);
-                cur = (rf[0] != REF_EMPTY) ? rf[0] : pop();
+                if (r3 != REF_EMPTY) push(r3, t3);
+                if (r2 != REF_EMPTY) push(r2, t2);
+                if (r1 != REF_EMPTY) push(r1, t1);
+                cur = (r0 != REF_EMPTY) ? r0 : pop();
             }
         } else if (m_leaf != 0ull) {
             // ---- leaf: own-box test + exact test of the leaf's first remaining triangle ------------------------
