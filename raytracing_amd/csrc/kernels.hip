@@ -271,7 +271,9 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
     auto pop = [&]() -> uint32_t {
         while (sp > 0) {
             --sp;
-            uint2 e = (sp < STACK_LDS) ? s_stack[sp * TRACE_THREADS + tid] : my_spill[sp - STACK_LDS];
+            uint2 e;   // (two explicit loads: a select between an LDS and a global address makes hipcc form a flat pointer)
+            if (sp < STACK_LDS) e = s_stack[sp * TRACE_THREADS + tid];
+            else e = my_spill[sp - STACK_LDS];
             if (!(__uint_as_float(e.y) > lim_n)) return e.x;
         }
         return REF_EMPTY;
@@ -482,9 +484,19 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 TRR_CSWAP(t0, r0, t1, r1) TRR_CSWAP(t2, r2, t3, r3) TRR_CSWAP(t0, r0, t2, r2)
                 TRR_CSWAP(t1, r1, t3, r3) TRR_CSWAP(t1, r1, t2, r2)
 #undef TRR_CSWAP
-                if (r3 != REF_EMPTY) push(r3, t3);
-                if (r2 != REF_EMPTY) push(r2, t2);
-                if (r1 != REF_EMPTY) push(r1, t1);
+                // far children go on the stack, farthest first.  Fast path: three unconditional LDS stores, the stack
+                // pointer advances only past valid entries (a slot above the top may hold garbage).
+                if (sp + 3 <= STACK_LDS) {
+                    const int i3 = sp, i2 = i3 + (r3 != REF_EMPTY ? 1 : 0), i1 = i2 + (r2 != REF_EMPTY ? 1 : 0);
+                    s_stack[i3 * TRACE_THREADS + tid] = make_uint2(r3, __float_as_uint(t3));
+                    s_stack[i2 * TRACE_THREADS + tid] = make_uint2(r2, __float_as_uint(t2));
+                    s_stack[i1 * TRACE_THREADS + tid] = make_uint2(r1, __float_as_uint(t1));
+                    sp = i1 + (r1 != REF_EMPTY ? 1 : 0);
+                } else {
+                    if (r3 != REF_EMPTY) push(r3, t3);
+                    if (r2 != REF_EMPTY) push(r2, t2);
+                    if (r1 != REF_EMPTY) push(r1, t1);
+                }
                 cur = (r0 != REF_EMPTY) ? r0 : pop();
             }
         } else if (m_leaf != 0ull) {
