@@ -543,7 +543,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     if (sc->ctx != ctx) return fail(ctx, TRR_ERR_INVALID, "render: scene belongs to another context");
     if (!sc->have_camera || !sc->have_settings) return fail(ctx, TRR_ERR_INVALID, "render: camera/settings not set");
     if (!(delta >= 0.0f)) return fail(ctx, TRR_ERR_INVALID, "render: delta must be >= 0");
-    if (max_depth > 255) return fail(ctx, TRR_ERR_INVALID, "render: max_depth above 255");
+    if (max_depth > 254) return fail(ctx, TRR_ERR_INVALID, "render: max_depth above 254");
     if (n_shards == 0 || shard >= n_shards) return fail(ctx, TRR_ERR_INVALID, "render: bad shard / n_shards");
     Tiling tl;
     if (!tiling_of(sc->camera.width, sc->camera.height, &tl))
@@ -669,6 +669,8 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         tio.counters = kc;
         tio.spill = (uint2*)ctx->spill.p;
         tio.work_counter = cw + CW_WORK + 0;
+        tio.term = (float*)ctx->term.p;
+        tio.nlev = (uint8_t*)ctx->nlev.p;
         tio.first_obj = ids_obj_dev;
         tio.first_tri = ids_tri_dev;
         ev_begin(0);
@@ -704,10 +706,11 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
             ev_end();
         }
         ResolveIO rio{};
-        rio.level = (const float*)ctx->level.p; rio.term = (const float*)ctx->term.p; rio.nlev = (const uint8_t*)ctx->nlev.p;
+        rio.level = (const float*)ctx->level.p; rio.term = (const float*)ctx->term.p; rio.term_out = (float*)ctx->term.p; rio.nlev = (const uint8_t*)ctx->nlev.p;
         rio.occ = (const int32_t*)ctx->occ.p; rio.strip = strip_dev;
         ev_begin(1);
-        launch_resolve(std::min<uint32_t>(aux_grid_max, (bp.n_pixels + 255) / 256), st, fp, bp, rio);
+        launch_resolve(std::min<uint32_t>(aux_grid_max * 4, (bp.n_samples + 255) / 256),
+                       std::min<uint32_t>(aux_grid_max, (bp.n_pixels + 255) / 256), st, fp, bp, rio);
         ev_end();
         HIPCHK(ctx, hipGetLastError());
         if (stats) HIPCHK(ctx, hipMemcpyAsync((char*)ctx->pinned + rb_stride * bi, ctx->counters.p, rb_stride, hipMemcpyDeviceToHost, st));

@@ -7,7 +7,8 @@
 //   for level = 0 .. max_depth-1:
 //     k_setup            HitRec -> shaded-hit record; emits L shadow rays + <=1 reflection ray   (mod.rs:124-153, 199-206)
 //     k_trace<QUEUE>     shadow rays + next level's reflection rays in ONE launch   (mod.rs:45-51, 96-114; object.rs:184-220)
-//   k_resolve            deepest-first evaluation of shade_impl per sample, mean over samples, RGB8  (mod.rs:141-211, render.rs:134-140)
+//   k_resolve_samples    deepest-first evaluation of shade_impl per sample that hit something   (mod.rs:141-211)
+//   k_resolve_pixels     mean over a pixel's samples, RGB8                                     (mod.rs:248-249, render.rs:134-140)
 //
 // Arithmetic is IEEE fp32 with the reference's operation order; build with -ffp-contract=off (Rust never
 // fuses a*b+c) and correctly rounded division / sqrt (hipcc default).  Comments cite the reference lines
@@ -162,6 +163,7 @@ DEV F3 primary_dir(const FrameParams& fp, uint32_t x, uint32_t y, uint32_t si) {
 // has finished are re-filled (ballot + one atomic per wavefront) once enough of them are idle.
 // ------------------------------------------------------------------------------------------------
 constexpr int TRACE_THREADS = 256;
+constexpr uint8_t NLEV_PENDING = 0xFF;   // nlev value of a camera sample whose hit waits for k_setup (max_depth <= 255 keeps it free)
 #ifdef TRR_WAVES_PER_EU
 #define TRR_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(TRR_WAVES_PER_EU, 8)))
 #else
@@ -308,7 +310,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                         rd = primary_dir(fp, pp.x, pp.y, si);
                         r_out = idx;
                         r_sample = pp.y * fp.width + pp.x;   // frame pixel index, used for the id buffers
-                        r_meta = 0;
+                        r_meta = idx;                        // RAYGEN: the sample index (term / nlev planes)
                     } else {
                         const RayRec* q = (idx < n_shadow) ? (io.shadow_q + idx) : (io.chain_q + (idx - n_shadow));
                         float4 a = *reinterpret_cast<const float4*>(q);
@@ -381,6 +383,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                         float4* dst = reinterpret_cast<float4*>(io.hits + r_out);
                         dst[0] = make_float4(g_u, g_v, g_w, __uint_as_float(g_slot));
                         dst[1] = make_float4(__uint_as_float(g_obj), __uint_as_float(tri_id), 0.0f, 0.0f);
+                        if (RAYGEN && first_cast) io.nlev[r_meta] = NLEV_PENDING;   // k_setup shades it at level 0
                     }
                     if (RAYGEN && first_cast && io.first_obj != nullptr) {
                         io.first_obj[r_sample] = g_obj;
@@ -395,6 +398,14 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                     if (is_shadow) {
                         uint32_t level = r_meta & 0xFFu, light = r_meta >> 16;
                         io.occ[((size_t)level * fp.n_lights + light) * bp.cap + r_sample] = -1;
+                    } else if (RAYGEN) {
+                        // mod.rs:119: a camera ray that hits nothing is skybox(ray.direction); finished here, no hit
+                        // record is written and k_setup skips the sample
+                        F3 c = skybox(fp, rd);
+                        io.term[0 * (size_t)bp.cap + r_meta] = c.x;
+                        io.term[1 * (size_t)bp.cap + r_meta] = c.y;
+                        io.term[2 * (size_t)bp.cap + r_meta] = c.z;
+                        io.nlev[r_meta] = 0;
                     } else {
                         float4* dst = reinterpret_cast<float4*>(io.hits + r_out);
                         dst[0] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
@@ -593,6 +604,7 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
         bool hit = false, reflective = false, spawn = false;
         F3 P = f3(0, 0, 0), N = f3(0, 0, 0), D = f3(0, 0, 0);
         uint32_t sample = 0;
+        if (LEVEL0 && valid && io.nlev[i] != NLEV_PENDING) valid = false;   // a miss, finished by k_trace<RAYGEN>
         if (valid) {
             if (LEVEL0) {
                 sample = i;
@@ -705,75 +717,89 @@ DEV uint8_t quantize(float c) {   // render.rs:136-138: (c * 255.0) as u8
     return (uint8_t)v;
 }
 
-__global__ void __launch_bounds__(256) k_resolve(FrameParams fp, BatchParams bp, ResolveIO io) {
+// Pass 1, one thread per SAMPLE: samples that hit something (nlev > 0) are evaluated deepest level first and their
+// colour replaces the terminal colour in `term`; misses (nlev == 0) already hold skybox(direction) there.
+__global__ void __launch_bounds__(256) k_resolve_samples(FrameParams fp, BatchParams bp, ResolveIO io) {
     const uint32_t L = fp.n_lights;
+    const size_t cap = bp.cap;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < bp.n_samples; s += gridDim.x * blockDim.x) {
+        const int n = io.nlev[s];
+        if (n == 0) continue;
+        F3 R = f3(0.0f, 0.0f, 0.0f);
+        {
+            bool need_term = false;
+            int32_t dm = __float_as_int(io.level[((size_t)(n - 1) * LEVEL_PLANES + 12) * cap + s]);
+            if (dm >= 0) {
+                int il = fp.mats[dm].illum;
+                need_term = (il == 3 || il == 4);
+            }
+            if (need_term) R = f3(io.term[s], io.term[cap + s], io.term[2 * cap + s]);
+        }
+        for (int k = n - 1; k >= 0; --k) {
+            const float* lv = io.level + (size_t)k * LEVEL_PLANES * cap + s;
+            F3 P = f3(lv[0], lv[cap], lv[2 * cap]);
+            F3 N = f3(lv[3 * cap], lv[4 * cap], lv[5 * cap]);
+            F3 D = f3(lv[6 * cap], lv[7 * cap], lv[8 * cap]);
+            F3 diff = f3(lv[9 * cap], lv[10 * cap], lv[11 * cap]);
+            int32_t mat = __float_as_int(lv[12 * cap]);
+            F3 spec = f3(0.9f, 0.9f, 0.9f);   // mod.rs:136-139
+            bool specular = false, reflective = false;
+            float ns = 1.0f;
+            if (mat >= 0) {
+                const MatRec* m = fp.mats + mat;
+                if (m->flags & 2u) spec = f3(m->ks[0], m->ks[1], m->ks[2]);
+                if (m->flags & 4u) ns = m->ns;
+                specular = (m->illum == 2);
+                reflective = (m->illum == 3 || m->illum == 4);
+            }
+            // mod.rs:141-146
+            F3 c = scale(cmul(f3(fp.ambient[0], fp.ambient[1], fp.ambient[2]), diff), fp.ambient_intensity);
+            for (uint32_t l = 0; l < L; ++l) {   // mod.rs:148 (order matters: c is read and written)
+                const LightRec* lt = fp.lights + l;
+                F3 lp = f3(lt->pos[0], lt->pos[1], lt->pos[2]);
+                F3 ld = normalize(lp - P);   // mod.rs:149
+                int32_t oc = io.occ[((size_t)k * L + l) * cap + s];
+                F3 trans;
+                if (oc == -1) trans = f3(1.0f, 1.0f, 1.0f);   // mod.rs:160
+                else {
+                    F3 okd = f3(1.0f, 1.0f, 1.0f);
+                    float odis = 1.0f;
+                    if (oc >= 0) {
+                        const MatRec* om = fp.mats + oc;
+                        if (om->flags & 1u) okd = f3(om->kd[0], om->kd[1], om->kd[2]);
+                        if (om->flags & 8u) odis = om->dissolve;
+                    }
+                    trans = scale(cmul(c, okd), odis);   // mod.rs:162-166
+                }
+                trans = cmul(trans, f3(lt->color[0], lt->color[1], lt->color[2]));   // mod.rs:169
+                if (norm(trans) < 0.01f) continue;                                   // mod.rs:171-173
+                float li = lt->intensity / norm_squared(lp - P);                     // mod.rs:176
+                float di = rmax(dot(ld, N), 0.0f) * li;                              // mod.rs:177
+                c = c + scale(cmul(diff, trans), di);                                // mod.rs:178
+                if (specular) {                                                      // mod.rs:181-196
+                    float sint = powf(rmax(dot(ld, reflect(neg(D), N)), 0.0f), ns) * li;
+                    c = c + scale(cmul(spec, trans), sint);
+                }
+                if (reflective) c = c + cmul(c, R);                                  // mod.rs:207
+            }
+            R = c;
+        }
+        io.term_out[s] = R.x;
+        io.term_out[cap + s] = R.y;
+        io.term_out[2 * cap + s] = R.z;
+    }
+}
+
+// Pass 2, one thread per PIXEL: sum of the pixel's samples in ascending order, mean (mod.rs:248-249), quantise
+// (render.rs:134-140), store into the shard's strip.
+__global__ void __launch_bounds__(256) k_resolve_pixels(FrameParams fp, BatchParams bp, ResolveIO io) {
     const size_t cap = bp.cap;
     for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < bp.n_pixels; pix += gridDim.x * blockDim.x) {
         F3 sum = f3(0.0f, 0.0f, 0.0f);
         F3 color = f3(0.0f, 0.0f, 0.0f);
         for (uint32_t si = 0; si < fp.spp; ++si) {
             uint32_t s = pix * fp.spp + si;
-            int n = io.nlev[s];
-            F3 R = f3(0.0f, 0.0f, 0.0f);
-            bool need_term = (n == 0);
-            if (n > 0) {
-                int32_t dm = __float_as_int(io.level[((size_t)(n - 1) * LEVEL_PLANES + 12) * cap + s]);
-                if (dm >= 0) {
-                    int il = fp.mats[dm].illum;
-                    need_term = (il == 3 || il == 4);
-                }
-            }
-            if (need_term) R = f3(io.term[s], io.term[cap + s], io.term[2 * cap + s]);
-            for (int k = n - 1; k >= 0; --k) {
-                const float* lv = io.level + (size_t)k * LEVEL_PLANES * cap + s;
-                F3 P = f3(lv[0], lv[cap], lv[2 * cap]);
-                F3 N = f3(lv[3 * cap], lv[4 * cap], lv[5 * cap]);
-                F3 D = f3(lv[6 * cap], lv[7 * cap], lv[8 * cap]);
-                F3 diff = f3(lv[9 * cap], lv[10 * cap], lv[11 * cap]);
-                int32_t mat = __float_as_int(lv[12 * cap]);
-                F3 spec = f3(0.9f, 0.9f, 0.9f);   // mod.rs:136-139
-                bool specular = false, reflective = false;
-                float ns = 1.0f;
-                if (mat >= 0) {
-                    const MatRec* m = fp.mats + mat;
-                    if (m->flags & 2u) spec = f3(m->ks[0], m->ks[1], m->ks[2]);
-                    if (m->flags & 4u) ns = m->ns;
-                    specular = (m->illum == 2);
-                    reflective = (m->illum == 3 || m->illum == 4);
-                }
-                // mod.rs:141-146
-                F3 c = scale(cmul(f3(fp.ambient[0], fp.ambient[1], fp.ambient[2]), diff), fp.ambient_intensity);
-                for (uint32_t l = 0; l < L; ++l) {   // mod.rs:148 (order matters: c is read and written)
-                    const LightRec* lt = fp.lights + l;
-                    F3 lp = f3(lt->pos[0], lt->pos[1], lt->pos[2]);
-                    F3 ld = normalize(lp - P);   // mod.rs:149
-                    int32_t oc = io.occ[((size_t)k * L + l) * cap + s];
-                    F3 trans;
-                    if (oc == -1) trans = f3(1.0f, 1.0f, 1.0f);   // mod.rs:160
-                    else {
-                        F3 okd = f3(1.0f, 1.0f, 1.0f);
-                        float odis = 1.0f;
-                        if (oc >= 0) {
-                            const MatRec* om = fp.mats + oc;
-                            if (om->flags & 1u) okd = f3(om->kd[0], om->kd[1], om->kd[2]);
-                            if (om->flags & 8u) odis = om->dissolve;
-                        }
-                        trans = scale(cmul(c, okd), odis);   // mod.rs:162-166
-                    }
-                    trans = cmul(trans, f3(lt->color[0], lt->color[1], lt->color[2]));   // mod.rs:169
-                    if (norm(trans) < 0.01f) continue;                                   // mod.rs:171-173
-                    float li = lt->intensity / norm_squared(lp - P);                     // mod.rs:176
-                    float di = rmax(dot(ld, N), 0.0f) * li;                              // mod.rs:177
-                    c = c + scale(cmul(diff, trans), di);                                // mod.rs:178
-                    if (specular) {                                                      // mod.rs:181-196
-                        float sint = powf(rmax(dot(ld, reflect(neg(D), N)), 0.0f), ns) * li;
-                        c = c + scale(cmul(spec, trans), sint);
-                    }
-                    if (reflective) c = c + cmul(c, R);                                  // mod.rs:207
-                }
-                R = c;
-            }
-            color = R;
+            color = f3(io.term[s], io.term[cap + s], io.term[2 * cap + s]);
             sum = sum + color;
         }
         if (fp.aa) color = unscale(sum, (float)fp.spp);   // mod.rs:248-249
@@ -841,8 +867,10 @@ void launch_setup(bool level0, uint32_t grid, hipStream_t st, const FrameParams&
     else hipLaunchKernelGGL((k_setup<false>), g, b, 0, st, fp, bp, io, lvl);
 }
 
-void launch_resolve(uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp, const ResolveIO& io) {
-    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, st, fp, bp, io);
+void launch_resolve(uint32_t grid_samples, uint32_t grid_pixels, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
+                    const ResolveIO& io) {
+    hipLaunchKernelGGL(k_resolve_samples, dim3(grid_samples), dim3(256), 0, st, fp, bp, io);
+    hipLaunchKernelGGL(k_resolve_pixels, dim3(grid_pixels), dim3(256), 0, st, fp, bp, io);
 }
 
 void launch_assemble(hipStream_t st, uint32_t width, uint32_t height, uint32_t bw, uint32_t bh, uint32_t nbx, uint32_t nby,
