@@ -70,7 +70,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is always created, also for N = 1, so that the
+    # gather / all-reduce path is the one exercised whenever the launcher is used
+    distributed = world > 1 or "RANK" in os.environ
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -79,11 +82,11 @@ def main():
     t0 = time.perf_counter()
     rt = Raytracer(scene, max_depth=args.max_depth, device=local_rank)
     upload_s = time.perf_counter() - t0
-    sr = ShardedRenderer(rt, rank, world)
+    sr = ShardedRenderer(rt, rank, world, use_dist=distributed)
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -100,14 +103,14 @@ def main():
         sr.render(stats=stats[k])
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # rays of the whole frame = sum over ranks of their shard's rays (deterministic per frame)
     my_rays = stats[-1].rays() if stats else 0
-    if world > 1:
+    if distributed:
         t = torch.tensor([my_rays], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         frame_rays = int(t.item())
@@ -184,7 +187,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     rt.close()
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

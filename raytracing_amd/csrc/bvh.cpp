@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -13,7 +14,9 @@ namespace trr {
 namespace {
 
 constexpr int NBINS = 16;
-constexpr uint32_t MAX_LEAF = 4;
+uint32_t MAX_LEAF = 4;       // (tunable for experiments: TRR_BVH_MAX_LEAF = 1..4)
+uint32_t ALWAYS_LEAF = 2;    // ranges of at most this many triangles are never split (TRR_BVH_ALWAYS_LEAF)
+float LEAF_BIAS = 1.5f;      // leaf preferred while leaf_cost <= split_cost + LEAF_BIAS * area (TRR_BVH_LEAF_BIAS)
 constexpr uint32_t PAR_MIN = 1u << 15;   // subtrees above this size may get their own thread
 
 struct BNode {
@@ -71,7 +74,7 @@ struct Builder {
         }
         nd.box = box;
         uint32_t cnt = hi - lo;
-        if (cnt <= 2) { make_leaf(nd, lo, hi); return; }
+        if (cnt <= ALWAYS_LEAF) { make_leaf(nd, lo, hi); return; }
 
         // binned SAH over the three axes
         float best_cost = INFINITY;
@@ -115,7 +118,7 @@ struct Builder {
         }
         if (cnt <= MAX_LEAF) {
             float leaf_cost = half_area(box) * (float)cnt;
-            if (best_axis < 0 || leaf_cost <= best_cost + 1.5f * half_area(box)) { make_leaf(nd, lo, hi); return; }
+            if (best_axis < 0 || leaf_cost <= best_cost + LEAF_BIAS * half_area(box)) { make_leaf(nd, lo, hi); return; }
         }
         uint32_t mid = lo;
         if (best_axis >= 0) {
@@ -216,6 +219,10 @@ void build_bvh4(const Box3* boxes, uint32_t n, uint32_t n_threads, BuildResult* 
     res->max_depth = 0;
     res->bounds = empty_box();
     if (n == 0) return;
+    if (const char* e = std::getenv("TRR_BVH_MAX_LEAF")) MAX_LEAF = (uint32_t)std::min(4, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("TRR_BVH_ALWAYS_LEAF")) ALWAYS_LEAF = (uint32_t)std::min(4, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("TRR_BVH_LEAF_BIAS")) LEAF_BIAS = (float)std::atof(e);
+    if (ALWAYS_LEAF > MAX_LEAF) ALWAYS_LEAF = MAX_LEAF;
     if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
     n_threads = std::min(n_threads, 64u);
 

@@ -78,14 +78,15 @@ def gather_strips_host(strip: np.ndarray, rank: int, world: int, group=None) -> 
 
 class ShardedRenderer:
     """One rank of a tile-sharded render.  ``raytracer`` is this rank's ``Raytracer`` (scene already uploaded to this
-    rank's GPU).  ``render()`` queues shard render -> gather -> (root) assemble on torch's current stream and returns
+    rank's GPU).  ``render()`` queues shard render -> gather -> (root) assemble on one side stream and returns
     the frame tensor [h, w, 3] u8 on the root's GPU (None on the other ranks); nothing is synchronised."""
 
-    def __init__(self, raytracer, rank: int = 0, world: int = 1, group=None):
+    def __init__(self, raytracer, rank: int = 0, world: int = 1, group=None, use_dist: bool = None):
         import torch
 
         self.rt = raytracer
         self.rank, self.world, self.group = int(rank), int(world), group
+        self.use_dist = (self.world > 1) if use_dist is None else bool(use_dist)
         self.device = torch.device("cuda", raytracer.ctx.device)
         self.sb = raytracer.strip_bytes(self.world)
         self.strip = torch.zeros(self.sb, dtype=torch.uint8, device=self.device)
@@ -94,21 +95,27 @@ class ShardedRenderer:
             self.strips = torch.zeros((self.world, self.sb), dtype=torch.uint8, device=self.device)
             self.frame = torch.zeros((raytracer.height, raytracer.width, 3), dtype=torch.uint8, device=self.device)
             self._views = [self.strips[i] for i in range(self.world)]
+        # A side stream of torch's: the library renders on it (torch's default stream has handle 0, which the C ABI
+        # reads as "the context's own stream"), the RCCL gather is ordered after the render because it is issued with
+        # this stream current, and so is the assemble kernel.
+        self.stream = torch.cuda.Stream(self.device)
+        torch.cuda.synchronize(self.device)
 
     def render(self, stats=None, counters: bool = False):
         import torch
         import torch.distributed as dist
 
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.rt.render_shard_device(self.rank, self.world, self.strip.data_ptr(), self.sb, stream=stream, stats=stats,
-                                    counters=counters)
-        if self.world > 1:
-            # the single exchange of the path: finished RGB8 strips to the root (RCCL over xGMI with backend nccl)
-            dist.gather(self.strip, self._views if self.is_root else None, dst=0, group=self.group)
-            src = self.strips
-        else:
-            src = self.strip
-        if not self.is_root:
-            return None
-        self.rt.assemble_device(self.world, src.data_ptr(), self.frame.data_ptr(), stream=stream)
+        with torch.cuda.stream(self.stream):
+            stream = self.stream.cuda_stream
+            self.rt.render_shard_device(self.rank, self.world, self.strip.data_ptr(), self.sb, stream=stream, stats=stats,
+                                        counters=counters)
+            if self.use_dist:
+                # the single exchange of the path: finished RGB8 strips to the root (RCCL over xGMI with backend nccl)
+                dist.gather(self.strip, self._views if self.is_root else None, dst=0, group=self.group)
+                src = self.strips
+            else:
+                src = self.strip
+            if not self.is_root:
+                return None
+            self.rt.assemble_device(self.world, src.data_ptr(), self.frame.data_ptr(), stream=stream)
         return self.frame
