@@ -185,7 +185,11 @@ constexpr float PRUNE_REL = TRR_PRUNE_REL;
 #ifndef TRR_NODE_BIAS
 #define TRR_NODE_BIAS 8
 #endif
-constexpr int NODE_BIAS = TRR_NODE_BIAS;   // a node step runs when 8ths-weighted inner lanes >= leaf lanes
+constexpr int NODE_BIAS = TRR_NODE_BIAS;
+#ifndef TRR_CHUNK_DIV
+#define TRR_CHUNK_DIV 4
+#endif
+constexpr uint32_t CHUNK_DIV = TRR_CHUNK_DIV;   // a claim takes 1/CHUNK_DIV of the remaining work per wavefront   // a node step runs when 8ths-weighted inner lanes >= leaf lanes
 
 
 // triangle.rs:53-85 + object.rs:201,206 for one 64-B TriRec (normal and |ab x ac| precomputed with the same
@@ -238,12 +242,18 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
         total = n_shadow + *io.n_chain;
     }
 
+    // a launch with little (or no) work: wavefronts beyond one per 64 items leave before touching the work counter
+    // (5120 same-address atomics cost ~40 us, which is most of an empty launch)
+    if ((blockIdx.x * (TRACE_THREADS / 64) + tid / 64) * 64u >= total) return;
+
     // ---- per-lane state (results go to memory as soon as a raycast ends; only the winner's slot/key stay live) ----
     bool active = false;
     bool exhausted = false, last_chunk = false;          // wave-uniform
     uint32_t w_next = 0, w_end = 0;                      // wave-uniform: this wavefront's claimed range of work items
-    // chunk: ~1/8 of a wavefront's fair share, between one wavefront's worth and 512 items
-    const uint32_t chunk = max(64u, min(512u, total / (gridDim.x * (TRACE_THREADS / 64) * 8u)));
+    // chunk (guided self-scheduling): a fraction of what is left per wavefront, between one wavefront's worth and 512
+    // items, so that claims are rare while there is plenty of work and fine-grained near the end of the launch
+    const uint32_t n_waves = gridDim.x * (TRACE_THREADS / 64);
+    uint32_t chunk = max(64u, min(512u, total / (n_waves * CHUNK_DIV)));
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 0);      // world ray (origin advances during the march)
     uint32_t r_out = 0, r_sample = 0, r_meta = 0;
     bool first_cast = true;                      // no raycast of this ray has finished yet
@@ -296,6 +306,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                     w_next = min(base, total);
                     w_end = min(base + chunk, total);
                     if (base + chunk >= total) last_chunk = true;
+                    chunk = max(64u, min(512u, (total - w_end) / (n_waves * CHUNK_DIV)));
                 }
                 const uint32_t take = min((uint32_t)nidle, w_end - w_next);
                 uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
