@@ -53,9 +53,17 @@ struct trr_ctx {
     std::string err;
     std::string desc;
     // work buffers (grown on demand, kept between renders)
-    uint32_t cap = 0, cap_lights = 0, cap_depth = 0;
-    DevBuf hits, level, term, nlev, occ, shadow_q, chain_q[2], counters, spill, strip, frame, ids_obj, ids_tri, dbg;
-    uint32_t spill_grid = 0;
+    // Batches of blocks are pipelined over MAX_LANES work sets, each with its own stream: the persistent trace kernels
+    // of one batch drain (few long rays left) while the next batch's kernels fill the freed CUs.
+    struct WorkSet {
+        DevBuf hits, level, term, nlev, occ, shadow_q, chain_q[2], counters, spill;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    static constexpr int MAX_LANES = 3;
+    WorkSet ws[MAX_LANES];
+    hipEvent_t fork = nullptr;
+    DevBuf strip, frame, ids_obj, ids_tri;
     std::vector<hipEvent_t> events;
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -92,7 +100,7 @@ static int fail(trr_ctx* ctx, int code, const std::string& msg) {
 static int ensure(trr_ctx* ctx, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return TRR_OK;
     if (b.p) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipDeviceSynchronize());
         HIPCHK(ctx, hipFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
@@ -149,6 +157,17 @@ int trr_create(int device_id, trr_ctx** out) {
         delete ctx;
         return fail(nullptr, TRR_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
+    for (auto& w : ctx->ws) {
+        if (hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) {
+            trr_destroy(ctx);
+            return fail(nullptr, TRR_ERR_DEVICE, "hipStreamCreate / hipEventCreate for a work set failed");
+        }
+    }
+    if (hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess) {
+        trr_destroy(ctx);
+        return fail(nullptr, TRR_ERR_DEVICE, "hipEventCreate failed");
+    }
     *out = ctx;
     return TRR_OK;
 }
@@ -156,11 +175,15 @@ int trr_create(int device_id, trr_ctx** out) {
 void trr_destroy(trr_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf* b : {&ctx->hits, &ctx->level, &ctx->term, &ctx->nlev, &ctx->occ, &ctx->shadow_q, &ctx->chain_q[0],
-                      &ctx->chain_q[1], &ctx->counters, &ctx->spill, &ctx->strip, &ctx->frame, &ctx->ids_obj, &ctx->ids_tri,
-                      &ctx->dbg})
-        release(*b);
+    (void)hipDeviceSynchronize();
+    for (auto& w : ctx->ws) {
+        for (DevBuf* b : {&w.hits, &w.level, &w.term, &w.nlev, &w.occ, &w.shadow_q, &w.chain_q[0], &w.chain_q[1], &w.counters, &w.spill})
+            release(*b);
+        if (w.done) (void)hipEventDestroy(w.done);
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+    }
+    if (ctx->fork) (void)hipEventDestroy(ctx->fork);
+    for (DevBuf* b : {&ctx->strip, &ctx->frame, &ctx->ids_obj, &ctx->ids_tri}) release(*b);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -441,7 +464,7 @@ int trr_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_ob
 void trr_scene_destroy(trr_scene* sc) {
     if (!sc) return;
     if (sc->ctx) (void)hipSetDevice(sc->ctx->device);
-    if (sc->ctx && sc->ctx->stream) (void)hipStreamSynchronize(sc->ctx->stream);
+    if (sc->ctx) (void)hipDeviceSynchronize();
     for (DevBuf* b : {&sc->nodes, &sc->tris, &sc->interp, &sc->objs, &sc->mats, &sc->texs, &sc->texels, &sc->lights, &sc->sky})
         release(*b);
     delete sc;
@@ -451,7 +474,7 @@ int trr_scene_set_instances(trr_scene* sc, const float* transforms, const float*
     if (!sc || !transforms || !inverses) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_set_instances: NULL argument");
     if (n_objects != sc->n_objs) return fail(sc->ctx, TRR_ERR_INVALID, "trr_scene_set_instances: object count mismatch");
     HIPCHK(sc->ctx, hipSetDevice(sc->ctx->device));
-    HIPCHK(sc->ctx, hipStreamSynchronize(sc->ctx->stream));
+    HIPCHK(sc->ctx, hipDeviceSynchronize());
     for (uint32_t i = 0; i < n_objects; ++i) fill_obj_matrices(sc->h_objs[i], transforms + 16 * i, inverses + 16 * i);
     return upload(sc->ctx, sc->objs, sc->h_objs.data(), sc->h_objs.size() * sizeof(ObjRec));
 }
@@ -460,7 +483,7 @@ int trr_scene_set_lights(trr_scene* sc, const trr_light* lights, uint32_t n_ligh
     if (!sc || (n_lights && !lights)) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_set_lights: NULL argument");
     if (n_lights > 0xFFFFu) return fail(sc->ctx, TRR_ERR_INVALID, "trr_scene_set_lights: more than 65535 lights");
     HIPCHK(sc->ctx, hipSetDevice(sc->ctx->device));
-    HIPCHK(sc->ctx, hipStreamSynchronize(sc->ctx->stream));
+    HIPCHK(sc->ctx, hipDeviceSynchronize());
     std::vector<LightRec> l(n_lights);
     for (uint32_t i = 0; i < n_lights; ++i) {
         for (int k = 0; k < 3; ++k) { l[i].pos[k] = lights[i].position[k]; l[i].color[k] = lights[i].color[k]; }
@@ -474,7 +497,7 @@ int trr_scene_set_lights(trr_scene* sc, const trr_light* lights, uint32_t n_ligh
 int trr_scene_set_settings(trr_scene* sc, const trr_settings* s) {
     if (!sc || !s) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_set_settings: NULL argument");
     HIPCHK(sc->ctx, hipSetDevice(sc->ctx->device));
-    HIPCHK(sc->ctx, hipStreamSynchronize(sc->ctx->stream));
+    HIPCHK(sc->ctx, hipDeviceSynchronize());
     sc->settings = *s;
     sc->settings.skybox_image.rgb = nullptr;   // borrowed pointer: not kept
     sc->sky_w = sc->sky_h = 0;
@@ -570,29 +593,36 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     }
     if ((uint64_t)bpix * spp > (1ull << 31)) return fail(ctx, TRR_ERR_INVALID, "render: block too large for one batch");
 
-    // ---- batch sizing ---------------------------------------------------------------------------------------
+    // ---- batch sizing: batches are pipelined over `lanes` work sets (each its own stream + buffers) -------------
+    const bool interactive = progress != nullptr || cancel_flag != nullptr;   // polled per batch: keep batches in order
     const uint64_t per_sample = 32 /*hits*/ + 4ull * LEVEL_PLANES * std::max(1u, max_depth) + 12 + 1 +
                                 4ull * L * std::max(1u, max_depth) + 32ull * L + 64;
-    const uint64_t budget = 24ull << 30;
-    uint64_t max_samples = std::min<uint64_t>(budget / per_sample, 1ull << 25);
     const uint64_t spb = (uint64_t)bpix * spp;
-    uint32_t blocks_per_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_owned, max_samples / spb));
+    const uint32_t lanes = interactive ? 1u : (uint32_t)std::min<uint64_t>(trr_ctx::MAX_LANES, n_owned);
+    const uint64_t budget = (24ull << 30) / lanes;
+    const uint64_t max_samples = std::min<uint64_t>(budget / per_sample, 1ull << 25);
+    // at least 2 batches per lane (when there are enough blocks) so that every lane's tail has something to hide behind
+    const uint64_t want_batches = interactive ? 1 : std::min<uint64_t>(n_owned, 2ull * lanes);
+    uint32_t blocks_per_batch = (uint32_t)std::max<uint64_t>(
+        1, std::min<uint64_t>((n_owned + want_batches - 1) / want_batches, max_samples / spb));
     const uint32_t cap = (uint32_t)(((uint64_t)blocks_per_batch * spb + 63) & ~63ull);
     const uint32_t D = std::max(1u, max_depth);
-    int rc;
-    if ((rc = ensure(ctx, ctx->hits, (size_t)cap * sizeof(HitRec))) || (rc = ensure(ctx, ctx->level, (size_t)cap * 4 * LEVEL_PLANES * D)) ||
-        (rc = ensure(ctx, ctx->term, (size_t)cap * 12)) || (rc = ensure(ctx, ctx->nlev, (size_t)cap)) ||
-        (rc = ensure(ctx, ctx->occ, (size_t)cap * 4 * std::max(1u, L) * D)) ||
-        (rc = ensure(ctx, ctx->shadow_q, (size_t)cap * sizeof(RayRec) * std::max(1u, L))) ||
-        (rc = ensure(ctx, ctx->chain_q[0], (size_t)cap * sizeof(RayRec))) ||
-        (rc = ensure(ctx, ctx->chain_q[1], (size_t)cap * sizeof(RayRec))) || (rc = ensure(ctx, ctx->counters, CW_WORDS * 4 + 64)))
-        return rc;
-
     // persistent trace grid: every CU gets as many 256-thread blocks as its registers / LDS admit
     const int bpc = std::min(trace_blocks_per_cu(true, count), trace_blocks_per_cu(false, count));
     const uint32_t trace_grid = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::max(1, std::min(bpc, 8));
-    if ((rc = ensure(ctx, ctx->spill, trace_spill_bytes(trace_grid)))) return rc;
     const uint32_t aux_grid_max = (uint32_t)ctx->n_cu * 8;
+    int rc;
+    for (uint32_t k = 0; k < lanes; ++k) {
+        trr_ctx::WorkSet& w = ctx->ws[k];
+        if ((rc = ensure(ctx, w.hits, (size_t)cap * sizeof(HitRec))) || (rc = ensure(ctx, w.level, (size_t)cap * 4 * LEVEL_PLANES * D)) ||
+            (rc = ensure(ctx, w.term, (size_t)cap * 12)) || (rc = ensure(ctx, w.nlev, (size_t)cap)) ||
+            (rc = ensure(ctx, w.occ, (size_t)cap * 4 * std::max(1u, L) * D)) ||
+            (rc = ensure(ctx, w.shadow_q, (size_t)cap * sizeof(RayRec) * std::max(1u, L))) ||
+            (rc = ensure(ctx, w.chain_q[0], (size_t)cap * sizeof(RayRec))) ||
+            (rc = ensure(ctx, w.chain_q[1], (size_t)cap * sizeof(RayRec))) || (rc = ensure(ctx, w.counters, CW_WORDS * 4 + 64)) ||
+            (rc = ensure(ctx, w.spill, trace_spill_bytes(trace_grid))))
+            return rc;
+    }
 
     FrameParams fp{};
     fp.nodes = (const Node4*)sc->nodes.p; fp.tris = (const TriRec*)sc->tris.p; fp.interp = (const InterpRec*)sc->interp.p;
@@ -620,12 +650,11 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     fp.shard = shard; fp.n_shards = n_shards;
     fp.delta = delta; fp.max_depth = max_depth;
 
-    uint32_t* cw = (uint32_t*)ctx->counters.p;
-    unsigned long long* kc = (unsigned long long*)((char*)ctx->counters.p + CW_WORDS * 4);
     const uint32_t n_batches = (n_owned + blocks_per_batch - 1) / blocks_per_batch;
     // pinned readback area: per batch CW_WORDS words + 8 kernel counters
     const size_t rb_stride = CW_WORDS * 4 + 64;
     if (ctx->pinned_bytes < rb_stride * n_batches) {
+        HIPCHK(ctx, hipDeviceSynchronize());
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         ctx->pinned = nullptr;
         ctx->pinned_bytes = 0;
@@ -635,90 +664,108 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     const bool timed = stats != nullptr;
     size_t n_events = 0;
     std::vector<uint8_t> ev_kind;   // 0 trace, 1 shade
-    auto ev_begin = [&](uint8_t kind) {
+    auto ev_begin = [&](uint8_t kind, hipStream_t s_) {
         if (!timed) return;
         hipEvent_t e = get_event(ctx, n_events);
-        if (e) (void)hipEventRecord(e, st);
+        if (e) (void)hipEventRecord(e, s_);
         ++n_events;
         ev_kind.push_back(kind);
     };
-    auto ev_end = [&]() {
+    auto ev_end = [&](hipStream_t s_) {
         if (!timed) return;
         hipEvent_t e = get_event(ctx, n_events);
-        if (e) (void)hipEventRecord(e, st);
+        if (e) (void)hipEventRecord(e, s_);
         ++n_events;
     };
+
+    // fork: with one lane everything stays on the caller's stream; with several, every lane stream waits for what
+    // the caller's stream has queued so far (the strip clear) and the caller's stream later waits for every lane
+    const bool forked = lanes > 1;
+    if (forked) {
+        HIPCHK(ctx, hipEventRecord(ctx->fork, st));
+        for (uint32_t k = 0; k < lanes; ++k) HIPCHK(ctx, hipStreamWaitEvent(ctx->ws[k].stream, ctx->fork, 0));
+    }
 
     uint32_t blocks_done = 0;
     int result = TRR_OK;
     uint32_t batches_run = 0;
     for (uint32_t bi = 0; bi < n_batches; ++bi) {
         if (cancel_flag && *cancel_flag) { result = TRR_ERR_CANCELLED; break; }   // render.rs:113
+        trr_ctx::WorkSet& w = ctx->ws[bi % lanes];
+        hipStream_t s_ = forked ? w.stream : st;
+        uint32_t* cw = (uint32_t*)w.counters.p;
+        unsigned long long* kc = (unsigned long long*)((char*)w.counters.p + CW_WORDS * 4);
         BatchParams bp{};
         bp.first_owned = bi * blocks_per_batch;
         bp.n_blocks = std::min(blocks_per_batch, n_owned - bp.first_owned);
         bp.n_pixels = bp.n_blocks * bpix;
         bp.n_samples = bp.n_pixels * spp;
         bp.cap = cap;
-        HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, CW_WORDS * 4 + 64, st));
+        HIPCHK(ctx, hipMemsetAsync(w.counters.p, 0, CW_WORDS * 4 + 64, s_));
         const uint32_t aux_grid = std::min<uint32_t>(aux_grid_max, (bp.n_samples + 255) / 256);
 
         TraceIO tio{};
-        tio.hits = (HitRec*)ctx->hits.p;
-        tio.occ = (int32_t*)ctx->occ.p;
+        tio.hits = (HitRec*)w.hits.p;
+        tio.occ = (int32_t*)w.occ.p;
         tio.counters = kc;
-        tio.spill = (uint2*)ctx->spill.p;
+        tio.spill = (uint2*)w.spill.p;
         tio.work_counter = cw + CW_WORK + 0;
-        tio.term = (float*)ctx->term.p;
-        tio.nlev = (uint8_t*)ctx->nlev.p;
+        tio.term = (float*)w.term.p;
+        tio.nlev = (uint8_t*)w.nlev.p;
         tio.first_obj = ids_obj_dev;
         tio.first_tri = ids_tri_dev;
-        ev_begin(0);
-        launch_trace(true, count, trace_grid, st, fp, bp, tio);
-        ev_end();
+        ev_begin(0, s_);
+        launch_trace(true, count, trace_grid, s_, fp, bp, tio);
+        ev_end(s_);
         // max_depth == 0: one setup pass turns every sample into skybox(ray.direction) (mod.rs:125-127), no secondary rays
         for (uint32_t lvl = 0; lvl < std::max(1u, max_depth); ++lvl) {
             SetupIO sio{};
-            sio.chain_in = (const RayRec*)ctx->chain_q[lvl & 1].p;
+            sio.chain_in = (const RayRec*)w.chain_q[lvl & 1].p;
             sio.n_chain_in = cw + CW_NCHAIN + lvl;
-            sio.hits = (const HitRec*)ctx->hits.p;
-            sio.level = (float*)ctx->level.p;
-            sio.term = (float*)ctx->term.p;
-            sio.nlev = (uint8_t*)ctx->nlev.p;
-            sio.shadow_out = (RayRec*)ctx->shadow_q.p;
+            sio.hits = (const HitRec*)w.hits.p;
+            sio.level = (float*)w.level.p;
+            sio.term = (float*)w.term.p;
+            sio.nlev = (uint8_t*)w.nlev.p;
+            sio.shadow_out = (RayRec*)w.shadow_q.p;
             sio.n_shadow_out = cw + CW_NSHADOW + lvl;
-            sio.chain_out = (RayRec*)ctx->chain_q[(lvl + 1) & 1].p;
+            sio.chain_out = (RayRec*)w.chain_q[(lvl + 1) & 1].p;
             sio.n_chain_out = cw + CW_NCHAIN + lvl + 1;
-            ev_begin(1);
-            launch_setup(lvl == 0, aux_grid, st, fp, bp, sio, lvl);
-            ev_end();
+            ev_begin(1, s_);
+            launch_setup(lvl == 0, aux_grid, s_, fp, bp, sio, lvl);
+            ev_end(s_);
             if (max_depth == 0) break;
             TraceIO t2 = tio;
-            t2.shadow_q = (const RayRec*)ctx->shadow_q.p;
+            t2.shadow_q = (const RayRec*)w.shadow_q.p;
             t2.n_shadow = cw + CW_NSHADOW + lvl;
-            t2.chain_q = (const RayRec*)ctx->chain_q[(lvl + 1) & 1].p;
+            t2.chain_q = (const RayRec*)w.chain_q[(lvl + 1) & 1].p;
             t2.n_chain = cw + CW_NCHAIN + lvl + 1;
             t2.work_counter = cw + CW_WORK + lvl + 1;
             t2.first_obj = nullptr;
             t2.first_tri = nullptr;
-            ev_begin(0);
-            launch_trace(false, count, trace_grid, st, fp, bp, t2);
-            ev_end();
+            ev_begin(0, s_);
+            launch_trace(false, count, trace_grid, s_, fp, bp, t2);
+            ev_end(s_);
         }
         ResolveIO rio{};
-        rio.level = (const float*)ctx->level.p; rio.term = (const float*)ctx->term.p; rio.term_out = (float*)ctx->term.p; rio.nlev = (const uint8_t*)ctx->nlev.p;
-        rio.occ = (const int32_t*)ctx->occ.p; rio.strip = strip_dev;
-        ev_begin(1);
+        rio.level = (const float*)w.level.p; rio.term = (const float*)w.term.p; rio.term_out = (float*)w.term.p;
+        rio.nlev = (const uint8_t*)w.nlev.p; rio.occ = (const int32_t*)w.occ.p; rio.strip = strip_dev;
+        ev_begin(1, s_);
         launch_resolve(std::min<uint32_t>(aux_grid_max * 4, (bp.n_samples + 255) / 256),
-                       std::min<uint32_t>(aux_grid_max, (bp.n_pixels + 255) / 256), st, fp, bp, rio);
-        ev_end();
+                       std::min<uint32_t>(aux_grid_max, (bp.n_pixels + 255) / 256), s_, fp, bp, rio);
+        ev_end(s_);
         HIPCHK(ctx, hipGetLastError());
-        if (stats) HIPCHK(ctx, hipMemcpyAsync((char*)ctx->pinned + rb_stride * bi, ctx->counters.p, rb_stride, hipMemcpyDeviceToHost, st));
+        if (stats) HIPCHK(ctx, hipMemcpyAsync((char*)ctx->pinned + rb_stride * bi, w.counters.p, rb_stride, hipMemcpyDeviceToHost, s_));
         ++batches_run;
         blocks_done += bp.n_blocks;
-        if (progress || cancel_flag) {
-            HIPCHK(ctx, hipStreamSynchronize(st));   // blocks of this batch are final: render.rs:143-149
+        if (interactive) {
+            HIPCHK(ctx, hipStreamSynchronize(s_));   // blocks of this batch are final: render.rs:143-149
             if (progress) progress(user, blocks_done, n_owned);
+        }
+    }
+    if (forked) {   // join
+        for (uint32_t k = 0; k < lanes; ++k) {
+            HIPCHK(ctx, hipEventRecord(ctx->ws[k].done, ctx->ws[k].stream));
+            HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ws[k].done, 0));
         }
     }
     if (stats) {
