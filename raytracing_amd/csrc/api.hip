@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -60,7 +61,7 @@ struct trr_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
     };
-    static constexpr int MAX_LANES = 3;
+    static constexpr int MAX_LANES = 6;
     WorkSet ws[MAX_LANES];
     hipEvent_t fork = nullptr;
     DevBuf strip, frame, ids_obj, ids_tri;
@@ -598,11 +599,14 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     const uint64_t per_sample = 32 /*hits*/ + 4ull * LEVEL_PLANES * std::max(1u, max_depth) + 12 + 1 +
                                 4ull * L * std::max(1u, max_depth) + 32ull * L + 64;
     const uint64_t spb = (uint64_t)bpix * spp;
-    const uint32_t lanes = interactive ? 1u : (uint32_t)std::min<uint64_t>(trr_ctx::MAX_LANES, n_owned);
+    uint32_t lanes_want = 3, batches_per_lane = 2;
+    if (const char* e = std::getenv("TRR_LANES")) lanes_want = (uint32_t)std::min(trr_ctx::MAX_LANES, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("TRR_BATCHES_PER_LANE")) batches_per_lane = (uint32_t)std::max(1, std::atoi(e));
+    const uint32_t lanes = interactive ? 1u : (uint32_t)std::min<uint64_t>(lanes_want, n_owned);
     const uint64_t budget = (24ull << 30) / lanes;
     const uint64_t max_samples = std::min<uint64_t>(budget / per_sample, 1ull << 25);
     // at least 2 batches per lane (when there are enough blocks) so that every lane's tail has something to hide behind
-    const uint64_t want_batches = interactive ? 1 : std::min<uint64_t>(n_owned, 2ull * lanes);
+    const uint64_t want_batches = interactive ? 1 : std::min<uint64_t>(n_owned, (uint64_t)batches_per_lane * lanes);
     uint32_t blocks_per_batch = (uint32_t)std::max<uint64_t>(
         1, std::min<uint64_t>((n_owned + want_batches - 1) / want_batches, max_samples / spb));
     const uint32_t cap = (uint32_t)(((uint64_t)blocks_per_batch * spb + 63) & ~63ull);

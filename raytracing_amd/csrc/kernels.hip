@@ -187,8 +187,12 @@ constexpr float PRUNE_REL = TRR_PRUNE_REL;
 #endif
 constexpr int NODE_BIAS = TRR_NODE_BIAS;
 #ifndef TRR_CHUNK_DIV
-#define TRR_CHUNK_DIV 4
+#define TRR_CHUNK_DIV 8
 #endif
+#ifndef TRR_CHUNK_MAX
+#define TRR_CHUNK_MAX 256
+#endif
+constexpr uint32_t CHUNK_MAX = TRR_CHUNK_MAX;
 constexpr uint32_t CHUNK_DIV = TRR_CHUNK_DIV;   // a claim takes 1/CHUNK_DIV of the remaining work per wavefront   // a node step runs when 8ths-weighted inner lanes >= leaf lanes
 
 
@@ -250,10 +254,10 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
     bool active = false;
     bool exhausted = false, last_chunk = false;          // wave-uniform
     uint32_t w_next = 0, w_end = 0;                      // wave-uniform: this wavefront's claimed range of work items
-    // chunk (guided self-scheduling): a fraction of what is left per wavefront, between one wavefront's worth and 512
+    // chunk (guided self-scheduling): a fraction of what is left per wavefront, between one wavefront's worth and CHUNK_MAX
     // items, so that claims are rare while there is plenty of work and fine-grained near the end of the launch
     const uint32_t n_waves = gridDim.x * (TRACE_THREADS / 64);
-    uint32_t chunk = max(64u, min(512u, total / (n_waves * CHUNK_DIV)));
+    uint32_t chunk = max(64u, min(CHUNK_MAX, total / (n_waves * CHUNK_DIV)));
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 0);      // world ray (origin advances during the march)
     uint32_t r_out = 0, r_sample = 0, r_meta = 0;
     bool first_cast = true;                      // no raycast of this ray has finished yet
@@ -306,7 +310,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                     w_next = min(base, total);
                     w_end = min(base + chunk, total);
                     if (base + chunk >= total) last_chunk = true;
-                    chunk = max(64u, min(512u, (total - w_end) / (n_waves * CHUNK_DIV)));
+                    chunk = max(64u, min(CHUNK_MAX, (total - w_end) / (n_waves * CHUNK_DIV)));
                 }
                 const uint32_t take = min((uint32_t)nidle, w_end - w_next);
                 uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
