@@ -199,8 +199,10 @@ struct Collapser {
                 nd.lox[k] = bx.lo[0]; nd.loy[k] = bx.lo[1]; nd.loz[k] = bx.lo[2];
                 nd.hix[k] = bx.hi[0]; nd.hiy[k] = bx.hi[1]; nd.hiz[k] = bx.hi[2];
             } else {
+                // (+inf .. +inf): (inf - o) * inv is +inf or -inf on both planes of every axis, so tmax > max(tmin, 0) is
+                // false for every ray and the kernel needs no separate "slot in use" test
                 nd.lox[k] = nd.loy[k] = nd.loz[k] = inf;
-                nd.hix[k] = nd.hiy[k] = nd.hiz[k] = -inf;
+                nd.hix[k] = nd.hiy[k] = nd.hiz[k] = inf;
                 nd.child[k] = REF_EMPTY;
             }
         }

@@ -479,7 +479,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 // [crate] Ray::intersects_aabb per child, same arithmetic as the per-triangle test below, so a parent
                 // box (exact union of its children) can never reject what a triangle's own box accepts.  Written with
                 // scalars and selects only (no arrays, no short-circuit branches): keeps the step branch-free.
-                // A NaN tmin keeps the child (and sorts it first).
+                // An unused child slot holds the box (+inf .. +inf), which fails the test for every ray; a NaN tmin keeps
+                // the child (NaN > x is false) and simply does not take part in the ordering.
 #define TRR_BOX(T, R, LX, LY, LZ, HX, HY, HZ, CH)                                                          \
     float T;                                                                                               \
     uint32_t R;                                                                                            \
@@ -489,9 +490,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
         float az = ((LZ) - oo.z) * oi.z, bz = ((HZ) - oo.z) * oi.z;                                        \
         float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));                                 \
         float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));                                 \
-        bool hit = ((CH) != REF_EMPTY) & (tmax > rmax(tmin, 0.0f)) & !(tmin > lim_n);                      \
-        float key = is_nan(tmin) ? -INFINITY : tmin;                                                       \
-        T = hit ? key : INFINITY;                                                                          \
+        bool hit = (tmax > rmax(tmin, 0.0f)) & !(tmin > lim_n);                                            \
+        T = hit ? tmin : INFINITY;                                                                         \
         R = hit ? (CH) : REF_EMPTY;                                                                        \
     }
                 TRR_BOX(t0, r0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x)
