@@ -128,9 +128,22 @@ def main():
         avg_ms = ms_trace / max(1, launches)
         bytes_per_launch = trace_bytes(cst) / max(1, cst.trace_launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic per launch: not measurable from inside the process; taken from the committed PMC passes of this same
+        # command (profiles/hbm_traffic.json, made by scripts/profile_pmc.sh + scripts/pmc_traffic.py), else null
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+                traffic = int(json.load(f)["kernels"]["k_trace"]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
+        frame_s = elapsed / args.steps
         roofline = {
             "bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            # launches of up to 3 batches overlap on separate streams, so launch durations add up to more than the
+            # frame; the second figure divides the same algorithmic bytes by the whole frame time instead
+            "achieved_over_frame_time": round(trace_bytes(cst) / frame_s / 1e9, 2),
+            "note": "algorithmic bytes; the working set is Infinity-Cache/L2 resident, see DESIGN.md section 4",
             "avg_launch_ms": round(avg_ms, 4), "launches_per_frame": launches // max(1, args.steps),
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "nodes_per_ray": round(cst.node_visits / max(1, cst.rays()), 2),
