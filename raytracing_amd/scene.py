@@ -99,6 +99,7 @@ class Skybox:
 
     color: Optional[np.ndarray] = None
     image: Optional[np.ndarray] = None   # uint8 [h, w, 3]
+    path: str = ""                       # where ``image`` came from (skybox.rs:7), for serialisation only
 
     @classmethod
     def default(cls) -> "Skybox":
@@ -156,6 +157,8 @@ class Object:
     translation: np.ndarray = field(default_factory=lambda: np.zeros(3, F32))
     rotation: np.ndarray = field(default_factory=lambda: np.array([0, 0, 0, 1], F32))
     scale: np.ndarray = field(default_factory=lambda: np.ones(3, F32))
+    material_name: str = ""   # names of the OBJ's `o` objects joined by ", " (object.rs:160-166); Hit.name, never shaded
+    path: str = ""            # file path as written in the scene YAML (object.rs:352-355)
 
     def __post_init__(self):
         self.triangles = np.ascontiguousarray(self.triangles, dtype=F32).reshape(-1, 24)

@@ -90,3 +90,57 @@ def scene_from_arrays(d) -> Scene:
     c = Camera(position=np.array(cam[0:3], np.float32), look_at=np.array(cam[3:6], np.float32), up=np.array(cam[6:9], np.float32),
                fov=float(cam[9]), resolution=tuple(meta["camera"]["resolution"]))
     return Scene(objects=objs, lights=lights, camera=c, settings=st)
+
+
+# ---- writes a Scene in the reference's on-disk formats (OBJ + MTL + PNG textures + scene YAML) so that the loader
+# (raytracing_amd/loader.py) can be fed real files; decimals are exact round-trip spellings of the f32 values --------
+def export_scene(sc: Scene, dirpath: str, yaml_name: str = "scene.yaml") -> str:
+    import os
+
+    from raytracing_amd.cli import write_png
+    from raytracing_amd.loader import scene_to_yaml
+
+    def r(x):
+        return repr(float(np.float32(x)))
+
+    os.makedirs(dirpath, exist_ok=True)
+    for oi, o in enumerate(sc.objects):
+        stem = f"obj{oi}"
+        with open(os.path.join(dirpath, stem + ".mtl"), "w") as f:
+            for k, m in enumerate(o.materials):
+                f.write(f"newmtl {m.name}\n")
+                if m.diffuse_color is not None:
+                    f.write("Kd " + " ".join(r(x) for x in m.diffuse_color) + "\n")
+                if m.specular_color is not None:
+                    f.write("Ks " + " ".join(r(x) for x in m.specular_color) + "\n")
+                if m.specular_exponent is not None:
+                    f.write(f"Ns {r(m.specular_exponent)}\n")
+                if m.dissolve is not None:
+                    f.write(f"d {r(np.float32(1.0) - np.float32(m.dissolve))}\n")
+                f.write(f"illum {m.illumination_model.value}\n")
+                if m.diffuse_texture is not None:
+                    write_png(os.path.join(dirpath, f"{stem}_m{k}.png"), m.diffuse_texture)
+                    f.write(f"map_Kd {stem}_m{k}.png\n")
+        with open(os.path.join(dirpath, stem + ".obj"), "w") as f:
+            f.write(f"mtllib {stem}.mtl\no {o.name or stem}\n")
+            prev = None
+            for ti, (t, mi) in enumerate(zip(o.triangles, o.material_index)):
+                if prev is None or mi != prev:
+                    f.write(f"g run{ti}\n")                    # a new group carries no material until `usemtl`
+                    if mi >= 0:
+                        f.write(f"usemtl {o.materials[mi].name}\n")
+                    prev = mi
+                for k in range(3):
+                    f.write("v " + " ".join(r(x) for x in t[3 * k:3 * k + 3]) + "\n")
+                    f.write("vn " + " ".join(r(x) for x in t[9 + 3 * k:12 + 3 * k]) + "\n")
+                    f.write("vt " + " ".join(r(x) for x in t[18 + 2 * k:20 + 2 * k]) + "\n")
+                f.write("f -3/-3/-3 -2/-2/-2 -1/-1/-1\n")
+        o.path = f"./{stem}.obj"
+    if sc.settings.skybox.image is not None:
+        sky = os.path.join(dirpath, "sky.png")
+        write_png(sky, sc.settings.skybox.image)
+        sc.settings.skybox.path = sky
+    path = os.path.join(dirpath, yaml_name)
+    with open(path, "w") as f:
+        f.write(scene_to_yaml(sc))
+    return path

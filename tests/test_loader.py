@@ -1,0 +1,403 @@
+"""Scene ingestion (raytracing_amd/loader.py) against the reference's load rules, on hand-written OBJ/MTL/YAML files.
+
+Expectations are derived by hand from src/scene/{mod,object,light,settings,camera,skybox}.rs (cited per test); the
+OBJ grammar rules marked [crate] restate the un-vendored `obj` 0.10 crate and are parity-unpinned (see loader.py).
+"""
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from raytracing_amd import loader
+from raytracing_amd.loader import SceneLoadError, load_object, load_scene, parse_mtl, parse_obj, scene_from_yaml
+from raytracing_amd.scene import Object
+
+F32 = np.float32
+
+QUAD_OBJ = """# a unit quad in the xz plane, one polygon, with normals and uvs
+mtllib quad.mtl
+o Quad
+v 0 0 0
+v 1 0 0
+v 1 0 1
+v 0 0 1
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vn 0 1 0
+usemtl red
+f 1/1/1 2/2/1 3/3/1 4/4/1
+"""
+
+QUAD_MTL = """newmtl red
+Kd 0.8 0.1 0.1
+Ks 0.5 0.5 0.5
+Ns 32
+Ni 1.45
+d 0.75
+illum 2
+"""
+
+CONFIG_YAML = """models:
+- filePath: ./quad.obj
+  position: {x: 0.7, y: -0.1, z: -0.5}
+  rotation: {x: 0.0, y: 90.0, z: 0.0}
+  scale: {x: 1.0, y: 2.0, z: 1.0}
+pointLights:
+- position: {x: -2.0, y: 3.5, z: -0.8}
+  Ke: {r: 0.5, g: 0.5, b: 0.5}
+  intensity: 40.0
+- position: {x: 5.5, y: 0.3, z: -4.5}
+  Ke: {r: 0.0, g: 0.0, b: 0.0}
+  intensity: 22.0
+camera:
+  position: {x: 3.7080245, y: 2.1147687, z: 7.0919194}
+  lookAt: {x: 3.3485944, y: 1.793123, z: 6.215932}
+  upVec: {x: 0.0, y: 1.0, z: 0.0}
+  fieldOfView: 63.02536
+  width: 1920
+  height: 1080
+extraArgs:
+"""
+
+
+def _write(dirpath, name, text):
+    p = os.path.join(str(dirpath), name)
+    os.makedirs(os.path.dirname(p), exist_ok=True)
+    with open(p, "w") as f:
+        f.write(text)
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ triangulate
+def test_fan_triangulation_order_and_attributes(tmp_path):
+    """object.rs:232-292: polygon (0,1,2,3) -> triangles (0,1,2), (0,2,3); normals/uvs from the named indices."""
+    _write(tmp_path, "quad.mtl", QUAD_MTL)
+    o = load_object(_write(tmp_path, "quad.obj", QUAD_OBJ))
+    assert o.triangles.shape == (2, 24)
+    t0, t1 = o.triangles
+    assert t0[0:9].tolist() == [0, 0, 0, 1, 0, 0, 1, 0, 1]
+    assert t1[0:9].tolist() == [0, 0, 0, 1, 0, 1, 0, 0, 1]
+    assert t0[9:18].tolist() == [0, 1, 0] * 3 and t1[9:18].tolist() == [0, 1, 0] * 3
+    assert t0[18:24].tolist() == [0, 0, 1, 0, 1, 1]
+    assert t1[18:24].tolist() == [0, 0, 1, 1, 0, 1]
+    assert o.material_index.tolist() == [0, 0]
+    assert o.name == "Quad" and o.material_name == "Quad"
+
+
+def test_pentagon_fan(tmp_path):
+    txt = "v 0 0 0\nv 2 0 0\nv 3 1 0\nv 1 2 0\nv -1 1 0\nf 1 2 3 4 5\n"
+    o = load_object(_write(tmp_path, "p.obj", txt))
+    idx = [[0, 1, 2], [0, 2, 3], [0, 3, 4]]
+    pts = np.array([[0, 0, 0], [2, 0, 0], [3, 1, 0], [1, 2, 0], [-1, 1, 0]], F32)
+    assert o.triangles.shape[0] == 3
+    for t, (a, b, c) in zip(o.triangles, idx):
+        assert np.array_equal(t[0:3], pts[a]) and np.array_equal(t[3:6], pts[b]) and np.array_equal(t[6:9], pts[c])
+    assert o.material_index.tolist() == [-1, -1, -1]            # no usemtl -> None (object.rs:117-134)
+    assert not o.triangles[:, 18:24].any()                      # no vt -> (0, 0) (object.rs:270-289)
+
+
+def test_computed_normal_is_a_minus_b_cross_a_minus_c_normalised(tmp_path):
+    """object.rs:237-243, bitwise: fp32 subtraction, cross, norm (x*x + y*y + z*z left to right), division."""
+    a, b, c = (F32(0.3), F32(-1.7), F32(2.1)), (F32(4.9), F32(0.2), F32(-0.6)), (F32(-2.2), F32(3.3), F32(0.45))
+    txt = "".join("v %r %r %r\n" % tuple(float(x) for x in p) for p in (a, b, c)) + "f 1 2 3\n"
+    o = load_object(_write(tmp_path, "t.obj", txt))
+    e1 = [F32(a[i] - b[i]) for i in range(3)]
+    e2 = [F32(a[i] - c[i]) for i in range(3)]
+    cr = [F32(F32(e1[1] * e2[2]) - F32(e1[2] * e2[1])), F32(F32(e1[2] * e2[0]) - F32(e1[0] * e2[2])),
+          F32(F32(e1[0] * e2[1]) - F32(e1[1] * e2[0]))]
+    n = np.sqrt(F32(F32(F32(cr[0] * cr[0]) + F32(cr[1] * cr[1])) + F32(cr[2] * cr[2])), dtype=F32)
+    want = np.array([F32(x / n) for x in cr], F32)
+    for k in range(3):
+        assert o.triangles[0, 9 + 3 * k:12 + 3 * k].tobytes() == want.tobytes()
+
+
+def test_degenerate_triangle_gets_zero_normal(tmp_path, caplog):
+    """try_normalize(f32::EPSILON) -> None -> (0, 0, 0) and a warning (object.rs:239-243, 144-146)."""
+    txt = "v 0 0 0\nv 1 1 1\nv 2 2 2\nv 0 0 1e-4\nv 1e-4 0 0\nf 1 2 3\nf 1 4 5\n"
+    with caplog.at_level("WARNING", logger="raytracing_amd.loader"):
+        o = load_object(_write(tmp_path, "d.obj", txt))
+    assert not o.triangles[0, 9:18].any()          # collinear: cross product is exactly zero
+    assert not o.triangles[1, 9:18].any()          # |cross| = 1e-8 <= f32::EPSILON
+    assert "Computed normals for 2 triangles is zero" in caplog.text
+    assert "No normals for 6 triangles" in caplog.text and "No UV for 6 triangles" in caplog.text
+
+
+def test_mixed_vertex_normals_fall_back_per_corner(tmp_path):
+    txt = "v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0.6 0 0.8\nf 1//1 2 3\n"
+    o = load_object(_write(tmp_path, "m.obj", txt))
+    assert np.array_equal(o.triangles[0, 9:12], np.array([0.6, 0, 0.8], F32))
+    # (a-b)x(a-c) = (-1,0,0)x(0,-1,0) = (0,0,1)
+    assert o.triangles[0, 12:15].tolist() == [0, 0, 1] and o.triangles[0, 15:18].tolist() == [0, 0, 1]
+
+
+def test_negative_indices_are_relative_to_elements_read_so_far(tmp_path):
+    txt = "v 0 0 0\nv 1 0 0\nv 0 1 0\nf -3 -2 -1\nv 5 5 5\nv 6 5 5\nv 5 6 5\nf -3 -2 -1\n"
+    o = load_object(_write(tmp_path, "n.obj", txt))
+    assert o.triangles[0, 0:9].tolist() == [0, 0, 0, 1, 0, 0, 0, 1, 0]
+    assert o.triangles[1, 0:9].tolist() == [5, 5, 5, 6, 5, 5, 5, 6, 5]
+
+
+def test_bad_indices_and_numbers_are_errors(tmp_path):
+    for txt in ("v 0 0 0\nf 1 2 3\n", "v 0 0 0\nf 0 0 0\n", "v 0 0\n", "v a b c\n", "v 0 0 0\nf 1/x 1 1\n"):
+        with pytest.raises(SceneLoadError):
+            load_object(_write(tmp_path, "bad.obj", txt))
+    with pytest.raises(SceneLoadError, match="Failed to load obj"):
+        load_object(os.path.join(str(tmp_path), "missing.obj"))
+
+
+# ------------------------------------------------------------------------------------------------ groups / materials
+def test_triangle_order_is_file_order_across_objects_and_groups(tmp_path):
+    """object.rs:111-142: objects -> groups -> polys; every [crate] grouping rule keeps faces in file order."""
+    txt = ("mtllib two.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\n"
+           "f 1 2 3\no A\nusemtl m1\nf 1 2 4\ng side\nf 1 3 4\nusemtl m2\nf 2 3 4\nusemtl m1\nf 4 3 2\no B\nf 3 2 1\n")
+    _write(tmp_path, "two.mtl", "newmtl m1\nKd 1 0 0\nnewmtl m2\nKd 0 1 0\n")
+    o = load_object(_write(tmp_path, "two.obj", txt))
+    want = [(1, 2, 3), (1, 2, 4), (1, 3, 4), (2, 3, 4), (4, 3, 2), (3, 2, 1)]
+    P = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], F32)
+    for t, (a, b, c) in zip(o.triangles, want):
+        assert np.array_equal(t[0:9], np.concatenate([P[a - 1], P[b - 1], P[c - 1]]))
+    # [crate]: the face before any usemtl has none; `g side` starts a group WITHOUT a material, and the `usemtl m2`
+    # that follows applies to the whole group, the face already in it included; `usemtl m1` then splits the group
+    assert o.material_index.tolist() == [-1, 0, 1, 1, 0, -1]
+    assert o.material_name == "default, A, B"
+
+
+def test_material_fields(tmp_path):
+    """object.rs:77-109: Kd/Ks/Ns/Ni as given, dissolve = 1 - d, illum validated."""
+    _write(tmp_path, "quad.mtl", QUAD_MTL)
+    m = load_object(_write(tmp_path, "quad.obj", QUAD_OBJ)).materials[0]
+    assert m.name == "red"
+    assert m.diffuse_color.tobytes() == np.array([0.8, 0.1, 0.1], F32).tobytes()
+    assert m.specular_color.tolist() == [0.5, 0.5, 0.5]
+    assert m.specular_exponent == 32.0 and m.refraction_index == float(F32(1.45))
+    assert m.dissolve == float(F32(1.0) - F32(0.75))
+    assert m.illumination_model.value == 2 and m.illumination_model.specular()
+    assert m.diffuse_texture is None
+
+
+def test_absent_material_fields_stay_none_and_bad_illum_defaults(tmp_path, caplog):
+    _write(tmp_path, "a.mtl", "newmtl bare\nnewmtl odd\nillum 11\nKa 1 1 1\nTf 1 1 1\n")
+    with caplog.at_level("WARNING", logger="raytracing_amd.loader"):
+        o = load_object(_write(tmp_path, "a.obj", "mtllib a.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl odd\nf 1 2 3\n"))
+    bare, odd = o.materials
+    assert (bare.diffuse_color, bare.specular_color, bare.specular_exponent, bare.dissolve) == (None, None, None, None)
+    assert bare.illumination_model.value == 0 and odd.illumination_model.value == 0      # object.rs:99-105
+    assert "Invalid illumination model: -1" in caplog.text and "Invalid illumination model: 11" in caplog.text
+    assert o.material_index.tolist() == [1]
+
+
+def test_materials_of_all_libraries_in_order_and_first_name_wins(tmp_path):
+    """object.rs:77-81 flat_map over material_libs; object.rs:127-129 `.position(name)` -> the first of that name."""
+    _write(tmp_path, "l1.mtl", "newmtl a\nKd 1 0 0\nnewmtl b\nKd 0 1 0\n")
+    _write(tmp_path, "l2.mtl", "newmtl b\nKd 0 0 1\nnewmtl c\nKd 1 1 1\n")
+    o = load_object(_write(tmp_path, "x.obj", "mtllib l1.mtl\nmtllib l2.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\n"
+                                               "usemtl c\nf 1 2 3\nusemtl b\nf 1 2 3\n"))
+    assert [m.name for m in o.materials] == ["a", "b", "b", "c"]
+    assert o.material_index.tolist() == [3, 1]
+
+
+def test_unknown_material_reference_is_fatal(tmp_path):
+    """An unresolved usemtl stays ObjMaterial::Ref and the reference panics (object.rs:121-123)."""
+    with pytest.raises(SceneLoadError, match="Material reference not supported: ghost"):
+        load_object(_write(tmp_path, "g.obj", "v 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl ghost\nf 1 2 3\n"))
+
+
+def test_missing_mtllib_is_fatal(tmp_path):
+    with pytest.raises(SceneLoadError, match="Failed to load materials"):
+        load_object(_write(tmp_path, "g.obj", "mtllib nope.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n"))
+
+
+def test_mtllib_with_spaces_is_one_library():
+    assert parse_obj("mtllib my  file.mtl\n").material_libs == ["my file.mtl"]
+
+
+def test_comments_continuations_and_ignored_directives():
+    d = parse_obj("v 0 0 0 # origin\nv 1 0 \\\n 0\nv 0 1 0\ns off\nl 1 2\nf 1 2 3 # tri\n")
+    assert d.position.shape == (3, 3) and d.position[1].tolist() == [1, 0, 0]
+    assert d.objects[0].groups[0].polys == [[(0, None, None), (1, None, None), (2, None, None)]]
+    m = parse_mtl("# c\nnewmtl x y\nKd 1 2 3 # trailing\nmap_Kd tex.png extra\n")
+    assert m[0].name == "x" and m[0].kd == [1, 2, 3] and m[0].map_kd == "tex.png"
+
+
+def test_texture_is_loaded_relative_to_the_obj_and_failure_only_warns(tmp_path, caplog):
+    """object.rs:87-98."""
+    from raytracing_amd.cli import write_png
+    img = (np.arange(4 * 5 * 3, dtype=np.uint8).reshape(4, 5, 3) * 3)
+    os.makedirs(os.path.join(str(tmp_path), "textures"))
+    write_png(os.path.join(str(tmp_path), "textures", "t.png"), img)
+    _write(tmp_path, "t.mtl", "newmtl a\nmap_Kd textures/t.png\nnewmtl b\nmap_Kd textures/none.png\n")
+    with caplog.at_level("WARNING", logger="raytracing_amd.loader"):
+        o = load_object(_write(tmp_path, "t.obj", "mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\n"))
+    assert np.array_equal(o.materials[0].diffuse_texture, img)
+    assert o.materials[1].diffuse_texture is None and "Failed to load texture" in caplog.text
+
+
+def test_object_name_rule():
+    """object.rs:41-54."""
+    assert loader.object_name("/a/b/car.obj") == "Car"
+    assert loader.object_name("floor.v2.obj") == "Floor"
+    assert loader.object_name("Already.obj") == "Already" and loader.object_name("") == ""
+
+
+# ------------------------------------------------------------------------------------------------ YAML
+def test_scene_yaml_conventions(tmp_path):
+    """The reference's own res/test/config.yaml layout (values restated as data): Ke normalised (light.rs:33),
+    degrees -> radians (camera.rs:75), euler degrees -> quaternion (object.rs:336-340), extraArgs null -> defaults."""
+    _write(tmp_path, "quad.mtl", QUAD_MTL)
+    _write(tmp_path, "quad.obj", QUAD_OBJ)
+    s = load_scene(_write(tmp_path, "config.yaml", CONFIG_YAML))
+    o = s.objects[0]
+    assert o.path == "./quad.obj" and o.name == "Quad" and len(o.triangles) == 2
+    assert o.translation.tobytes() == np.array([0.7, -0.1, -0.5], F32).tobytes()
+    assert o.scale.tolist() == [1, 2, 1]
+    assert o.rotation.tobytes() == Object.quaternion_from_euler_degrees(0.0, 90.0, 0.0).tobytes()
+    np.testing.assert_allclose(o.rotation, [0, math.sqrt(0.5), 0, math.sqrt(0.5)], atol=1e-7)
+
+    l0, l1 = s.lights
+    half = F32(0.5)
+    n = np.sqrt(F32(F32(half * half + half * half) + half * half), dtype=F32)
+    assert l0.color.tobytes() == np.array([half / n] * 3, F32).tobytes() and l0.intensity == 40.0
+    assert l1.color.tolist() == [0, 0, 0]                       # try_normalize(0.0) fails on the zero vector -> default
+    assert s.camera.resolution == (1920, 1080)
+    assert F32(s.camera.fov) == F32(F32(63.02536) * F32(F32(np.pi) / F32(180.0)))
+    assert s.camera.position.tobytes() == np.array([3.7080245, 2.1147687, 7.0919194], F32).tobytes()
+    # Settings::default() (settings.rs:14-25)
+    assert s.settings.samples == 1 and not s.settings.anti_aliasing and s.settings.max_bounces == 4
+    assert abs(s.settings.ambient_intensity - 0.2) < 1e-9
+    assert s.settings.skybox.color.tobytes() == np.array([0.16, 0.16, 0.16], F32).tobytes()
+
+
+EXTRA = """extraArgs:
+  max_bounces: 7
+  samples: 16
+  ambient_color: {r: 0.3, g: 0.4, b: 0.0}
+  skybox: !Color [0.1, 0.2, 0.3]
+  anti_aliasing: true
+"""
+
+
+def _yaml_with(extra):
+    return CONFIG_YAML.replace("extraArgs:\n", extra)
+
+
+def test_extra_args(tmp_path):
+    """settings.rs:46-58: colour normalised, intensity = its norm; SkyboxDef::Color (skybox.rs:22-41)."""
+    _write(tmp_path, "quad.mtl", QUAD_MTL)
+    _write(tmp_path, "quad.obj", QUAD_OBJ)
+    s = load_scene(_write(tmp_path, "c.yaml", _yaml_with(EXTRA)))
+    st = s.settings
+    assert (st.max_bounces, st.samples, st.anti_aliasing) == (7, 16, True)
+    c = np.array([0.3, 0.4, 0.0], F32)
+    n = np.sqrt(F32(F32(c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]), dtype=F32)
+    assert st.ambient_color.tobytes() == (c / n).astype(F32).tobytes() and F32(st.ambient_intensity) == n
+    assert st.skybox.image is None and st.skybox.color.tobytes() == np.array([0.1, 0.2, 0.3], F32).tobytes()
+    # the single-key map spelling of the same enum
+    s2 = load_scene(_write(tmp_path, "c2.yaml", _yaml_with(EXTRA.replace("!Color [0.1, 0.2, 0.3]", "{Color: [0.1, 0.2, 0.3]}"))))
+    assert s2.settings.skybox.color.tobytes() == st.skybox.color.tobytes()
+
+
+def test_broken_or_missing_extra_args_fall_back_to_defaults(tmp_path, caplog):
+    """mod.rs:100-110."""
+    _write(tmp_path, "quad.mtl", QUAD_MTL)
+    _write(tmp_path, "quad.obj", QUAD_OBJ)
+    with caplog.at_level("WARNING", logger="raytracing_amd.loader"):
+        s = load_scene(_write(tmp_path, "c.yaml", _yaml_with(EXTRA.replace("  samples: 16\n", ""))))
+    assert "Failed to deserialize extraArgs" in caplog.text
+    assert s.settings.samples == 1 and not s.settings.anti_aliasing
+    s = load_scene(_write(tmp_path, "d.yaml", CONFIG_YAML.replace("extraArgs:\n", "")))
+    assert s.settings.max_bounces == 4
+
+
+def test_skybox_image_path(tmp_path):
+    """skybox.rs:57-64: image::open(path).into_rgb8(); the path is NOT resolved against the YAML."""
+    from raytracing_amd.cli import write_png
+    _write(tmp_path, "quad.mtl", QUAD_MTL)
+    _write(tmp_path, "quad.obj", QUAD_OBJ)
+    img = np.random.default_rng(3).integers(0, 256, (6, 12, 3), dtype=np.uint8)
+    sky = os.path.join(str(tmp_path), "sky.png")
+    write_png(sky, img)
+    s = load_scene(_write(tmp_path, "c.yaml", _yaml_with(EXTRA.replace("!Color [0.1, 0.2, 0.3]", f"!Path {sky}"))))
+    assert s.settings.skybox.color is None and np.array_equal(s.settings.skybox.image, img)
+    # a skybox that cannot be opened fails SettingsDef -> defaults (mod.rs:100-110)
+    s = load_scene(_write(tmp_path, "e.yaml", _yaml_with(EXTRA.replace("!Color [0.1, 0.2, 0.3]", "!Path nowhere.exr"))))
+    assert s.settings.skybox.image is None and s.settings.samples == 1
+
+
+@pytest.mark.parametrize("broken, msg", [
+    (lambda y: y.replace("models:", "modelz:"), "missing field `models`"),
+    (lambda y: y.replace("pointLights:", "lights:"), "missing field `pointLights`"),
+    (lambda y: y.replace("camera:", "cam:"), "missing field `camera`"),
+    (lambda y: y.replace("  fieldOfView: 63.02536\n", ""), "fieldOfView"),
+    (lambda y: y.replace("  intensity: 40.0\n", ""), "intensity"),
+    (lambda y: y.replace("  width: 1920", "  width: -3"), "width"),
+    (lambda y: y.replace("filePath: ./quad.obj", "filePath: ./absent.obj"), "Failed to load obj"),
+    (lambda y: y + "  - [", "Failed to deserialize"),
+])
+def test_required_fields(tmp_path, broken, msg):
+    _write(tmp_path, "quad.mtl", QUAD_MTL)
+    _write(tmp_path, "quad.obj", QUAD_OBJ)
+    with pytest.raises(SceneLoadError, match=msg):
+        load_scene(_write(tmp_path, "c.yaml", broken(CONFIG_YAML)))
+    with pytest.raises(SceneLoadError, match="Failed to read file"):
+        load_scene(os.path.join(str(tmp_path), "none.yaml"))
+
+
+def test_yaml_round_trip(tmp_path):
+    """The reference's Serialize impls (editor 'save'): what is written loads back to the same scene values."""
+    _write(tmp_path, "quad.mtl", QUAD_MTL)
+    _write(tmp_path, "quad.obj", QUAD_OBJ)
+    # (pitch = 90 degrees is the euler singularity: asin loses half the digits there, in the reference too)
+    text = _yaml_with(EXTRA).replace("rotation: {x: 0.0, y: 90.0, z: 0.0}", "rotation: {x: 20.0, y: 35.0, z: -50.0}")
+    s = load_scene(_write(tmp_path, "c.yaml", text))
+    s2 = load_scene(_write(tmp_path, "c_saved.yaml", loader.scene_to_yaml(s)))
+    assert np.array_equal(s2.objects[0].triangles, s.objects[0].triangles)
+    np.testing.assert_allclose(s2.objects[0].rotation, s.objects[0].rotation, atol=1e-6)
+    assert s2.objects[0].translation.tobytes() == s.objects[0].translation.tobytes()
+    for a, b in zip(s.lights, s2.lights):
+        np.testing.assert_allclose(a.color, b.color, atol=1e-6)
+        assert a.intensity == b.intensity and a.position.tobytes() == b.position.tobytes()
+    assert abs(s2.camera.fov - s.camera.fov) < 1e-6 and s2.camera.resolution == s.camera.resolution
+    np.testing.assert_allclose(s2.settings.ambient_color, s.settings.ambient_color, atol=1e-6)
+    assert abs(s2.settings.ambient_intensity - s.settings.ambient_intensity) < 1e-6
+    assert (s2.settings.samples, s2.settings.anti_aliasing, s2.settings.max_bounces) == (16, True, 7)
+    assert s2.settings.skybox.color.tobytes() == s.settings.skybox.color.tobytes()
+
+
+# ------------------------------------------------------------------------------------------------ export -> load identity
+def test_exported_standin_scene_loads_back_bit_identical(tmp_path):
+    """tests/_util.export_scene writes a Scene as OBJ/MTL/YAML (shortest round-trip decimals); the loader must return
+    the same triangles in the same order, the same material indices and the same material values."""
+    from raytracing_amd import standin
+    from tests._util import export_scene
+    src = standin.parity_scene(64, 48)
+    path = export_scene(src, str(tmp_path))
+    got = load_scene(path)
+    assert len(got.objects) == len(src.objects)
+    for a, b in zip(src.objects, got.objects):
+        assert a.triangles.tobytes() == b.triangles.tobytes()
+        assert a.material_index.tolist() == b.material_index.tolist()
+        assert len(a.materials) == len(b.materials)
+        for ma, mb in zip(a.materials, b.materials):
+            for fld in ("diffuse_color", "specular_color"):
+                va, vb = getattr(ma, fld), getattr(mb, fld)
+                assert (va is None) == (vb is None) and (va is None or va.astype(F32).tobytes() == vb.tobytes())
+            assert ma.illumination_model == mb.illumination_model
+            assert (ma.diffuse_texture is None) == (mb.diffuse_texture is None)
+            if ma.diffuse_texture is not None:
+                assert np.array_equal(ma.diffuse_texture, mb.diffuse_texture)
+        assert a.translation.tobytes() == b.translation.tobytes() and a.scale.tobytes() == b.scale.tobytes()
+
+
+def test_png_writer_round_trip(tmp_path):
+    from raytracing_amd.cli import write_png
+    img = np.random.default_rng(1).integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    p = os.path.join(str(tmp_path), "x.png")
+    write_png(p, img)
+    with open(p, "rb") as f:
+        head = f.read(24)
+    assert head[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">II", head[16:24]) == (53, 37)
+    assert np.array_equal(loader.load_image_rgb8(p), img)
