@@ -8,6 +8,9 @@ reference's hard-coded value, render.rs:105), 4 point lights of res/test/config.
 every rank renders its blocks of the reference's 20x20 block grid (block id % N == rank) into a device strip, one
 gather brings the strips to rank 0, rank 0 de-interleaves them into the row-major RGB8 frame.  The frame is the
 same for every N (strong scaling); scene, BVH and all work buffers are resident in HBM before the timed region.
+Consecutive frames alternate between two buffer sets / render streams (--frames-in-flight 2), so the head of frame k+1
+overlaps the tail of frame k; ms_per_step is elapsed / K (throughput), roofline.frame_latency_ms is one frame's own
+first-kernel-start to last-kernel-end time.
 
 Rays are counted by the rule of SURVEY.md section 8(d) (primaries + one shadow query per shaded hit and light + one
 reflection per reflective hit + transparency-march queries); the CPU baseline is credited the same rays for the
@@ -47,6 +50,8 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--max-depth", type=int, default=5)
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="buffer sets / render streams alternated by consecutive frames (1 = each frame waits for the previous one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "16")))
     args = ap.parse_args()
@@ -82,7 +87,7 @@ def main():
     t0 = time.perf_counter()
     rt = Raytracer(scene, max_depth=args.max_depth, device=local_rank)
     upload_s = time.perf_counter() - t0
-    sr = ShardedRenderer(rt, rank, world, use_dist=distributed)
+    sr = ShardedRenderer(rt, rank, world, use_dist=distributed, frames_in_flight=args.frames_in_flight)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -100,9 +105,10 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        sr.render(stats=stats[k])
+        sr.render(stats=stats[k], defer_stats=True)   # events are recorded now, read after the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
+    rt.ctx.collect_stats()
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -148,6 +154,7 @@ def main():
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "nodes_per_ray": round(cst.node_visits / max(1, cst.rays()), 2),
             "tris_per_ray": round(cst.tri_tests / max(1, cst.rays()), 2),
+            "frame_latency_ms": round(sum(s.ms_total for s in stats) / args.steps, 3),
             "trace_ms_per_frame": round(ms_trace / args.steps, 3),
             "shade_ms_per_frame": round(sum(s.ms_shade for s in stats) / args.steps, 3),
         }
@@ -195,7 +202,8 @@ def main():
             "config": {"workload": f"car_objs stand-in (procedural, {scene.triangle_count()} triangles, one object) "
                                    f"{args.width}x{args.height}, {args.spp} spp, max_depth {args.max_depth} "
                                    f"(reflection depth {args.max_depth - 1}), 4 lights, tiles sharded over {world} GPU(s)",
-                       "rays_per_frame": frame_rays, "scene_upload_s": round(upload_s, 2)},
+                       "rays_per_frame": frame_rays, "scene_upload_s": round(upload_s, 2),
+                       "frames_in_flight": args.frames_in_flight},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -148,6 +148,9 @@ int trr_scene_set_camera(trr_scene* scene, const trr_camera* camera);
 
 /* ---- render --------------------------------------------------------------------------------- */
 #define TRR_FLAG_COUNTERS 1u   /* also count node visits / box tests / triangle tests (slower kernel build) */
+#define TRR_FLAG_DEFER_STATS 2u /* trr_render_shard_device with stats_out: do not wait for the frame; *stats_out is
+                                 * filled by the next trr_collect_stats (stats_out must stay valid until then).  Lets
+                                 * a caller keep several frames in flight and still get per-launch timings. */
 
 /* Replaces the block loop of RenderingThread::run (render.rs:103-152) for the whole frame: writes
  * row-major RGB8 (width*height*3, remainder strip left 0,0,0 as render.rs:100-102) into host memory.
@@ -175,6 +178,10 @@ int trr_assemble_device(trr_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
                         const void* strips_dev, void* frame_dev, void* stream);
 /* Blocks until everything queued on the context's stream (or `stream`) has finished. */
 int trr_synchronize(trr_ctx* ctx, void* stream);
+/* Waits for every frame rendered with TRR_FLAG_DEFER_STATS and fills their trr_stats (ms_total = device time from
+ * the frame's first kernel start to its last kernel end).  The reference's only statistic is Render.time
+ * (render.rs:188-190); per-launch timing exists for the roofline figures of bench.py. */
+int trr_collect_stats(trr_ctx* ctx);
 
 /* ---- host math helpers (restatements of nalgebra for non-Rust hosts) -------------------------- */
 /* Object::transform() (object.rs:177-182) and its 4x4 inverse, column-major; rotation = unit quaternion

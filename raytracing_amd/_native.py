@@ -20,6 +20,7 @@ TRR_ERR_NOMEM = -5
 
 TRR_MAT_HAS_KD, TRR_MAT_HAS_KS, TRR_MAT_HAS_NS, TRR_MAT_HAS_DISSOLVE = 1, 2, 4, 8
 TRR_FLAG_COUNTERS = 1
+TRR_FLAG_DEFER_STATS = 2
 
 
 class MaterialDesc(C.Structure):
@@ -73,7 +74,7 @@ PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)
 EXPORTS = [
     "trr_create", "trr_destroy", "trr_last_error", "trr_scene_create", "trr_scene_destroy", "trr_scene_set_instances",
     "trr_scene_set_lights", "trr_scene_set_settings", "trr_scene_set_camera", "trr_render", "trr_render_shard_device",
-    "trr_strip_bytes", "trr_assemble_device", "trr_synchronize", "trr_object_matrices", "trr_camera_ray", "trr_version",
+    "trr_strip_bytes", "trr_assemble_device", "trr_synchronize", "trr_collect_stats", "trr_object_matrices", "trr_camera_ray", "trr_version",
 ]
 
 
@@ -134,6 +135,8 @@ def lib() -> C.CDLL:
     L.trr_assemble_device.argtypes = [vp, u32, u32, u32, vp, vp, vp]
     L.trr_synchronize.restype = i32
     L.trr_synchronize.argtypes = [vp, vp]
+    L.trr_collect_stats.restype = i32
+    L.trr_collect_stats.argtypes = [vp]
     L.trr_object_matrices.restype = i32
     L.trr_object_matrices.argtypes = [vp, vp, vp, vp, vp]
     L.trr_camera_ray.restype = None

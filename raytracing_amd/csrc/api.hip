@@ -66,8 +66,24 @@ struct trr_ctx {
     hipEvent_t fork = nullptr;
     DevBuf strip, frame, ids_obj, ids_tri;
     std::vector<hipEvent_t> events;
-    void* pinned = nullptr;
-    size_t pinned_bytes = 0;
+    size_t events_used = 0;              // events handed to frames whose statistics are still pending
+    // pinned read-back chunks (queue counters + kernel counters of one frame each), reused once collected
+    struct Pinned {
+        void* p = nullptr;
+        size_t bytes = 0;
+        bool in_use = false;
+    };
+    std::vector<Pinned> pinned;
+    // a frame rendered with TRR_FLAG_DEFER_STATS: everything trr_collect_stats needs to fill *out later
+    struct PendingStats {
+        trr_stats* out = nullptr;
+        size_t ev_first = 0, ev_count = 0;
+        std::vector<uint8_t> ev_kind;
+        int pinned_slot = -1;
+        uint32_t batches = 0, blocks_per_batch = 0, n_owned = 0, bpix = 0, spp = 0, max_depth = 0, blocks_done = 0;
+        hipStream_t caller_stream = nullptr;
+    };
+    std::vector<PendingStats> pending;
 };
 
 struct trr_scene {
@@ -126,6 +142,8 @@ static int upload(trr_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
     if (bytes) HIPCHK(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
     return TRR_OK;
 }
+
+static void finish_stats(trr_ctx* ctx, const trr_ctx::PendingStats& f);
 
 // ---- extern "C" ---------------------------------------------------------------------------------------------
 extern "C" {
@@ -186,9 +204,28 @@ void trr_destroy(trr_ctx* ctx) {
     if (ctx->fork) (void)hipEventDestroy(ctx->fork);
     for (DevBuf* b : {&ctx->strip, &ctx->frame, &ctx->ids_obj, &ctx->ids_tri}) release(*b);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
-    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto& pn : ctx->pinned)
+        if (pn.p) (void)hipHostFree(pn.p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int trr_collect_stats(trr_ctx* ctx) {
+    if (!ctx) return fail(nullptr, TRR_ERR_INVALID, "trr_collect_stats: ctx is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = TRR_OK;
+    for (auto& f : ctx->pending) {
+        // the frame's last work is on its caller's stream (the join), its read-backs on the lane streams before that
+        hipError_t e = hipStreamSynchronize(f.caller_stream);
+        for (auto& w : ctx->ws)
+            if (e == hipSuccess) e = hipStreamSynchronize(w.stream);
+        if (e == hipSuccess) finish_stats(ctx, f);
+        else rc = fail(ctx, TRR_ERR_DEVICE, std::string("trr_collect_stats: ") + hipGetErrorString(e));
+        ctx->pinned[f.pinned_slot].in_use = false;
+    }
+    ctx->pending.clear();
+    ctx->events_used = 0;
+    return rc;
 }
 
 int trr_synchronize(trr_ctx* ctx, void* stream) {
@@ -558,6 +595,53 @@ static hipEvent_t get_event(trr_ctx* ctx, size_t i) {
 // [CW_NSHADOW + lvl] shadow rays emitted at level lvl, [CW_NCHAIN + lvl] chain rays entering level lvl;
 // the 64-bit kernel counters follow at byte offset CW_WORDS*4.
 enum { CW_WORK = 0, CW_NSHADOW = 288, CW_NCHAIN = 576, CW_WORDS = 1024 };
+static constexpr size_t RB_STRIDE = CW_WORDS * 4 + 64;   // per batch: queue counters + 8 kernel counters
+
+static int acquire_pinned(trr_ctx* ctx, size_t bytes, int* slot) {
+    for (size_t i = 0; i < ctx->pinned.size(); ++i)
+        if (!ctx->pinned[i].in_use && ctx->pinned[i].bytes >= bytes) {
+            ctx->pinned[i].in_use = true;
+            *slot = (int)i;
+            return TRR_OK;
+        }
+    trr_ctx::Pinned pn;
+    HIPCHK(ctx, hipHostMalloc(&pn.p, bytes, hipHostMallocDefault));
+    pn.bytes = bytes;
+    pn.in_use = true;
+    ctx->pinned.push_back(pn);
+    *slot = (int)ctx->pinned.size() - 1;
+    return TRR_OK;
+}
+
+// Fills *f.out from the frame's read-back counters and events; the frame's work must have completed.
+static void finish_stats(trr_ctx* ctx, const trr_ctx::PendingStats& f) {
+    trr_stats* stats = f.out;
+    const char* base = (const char*)ctx->pinned[f.pinned_slot].p;
+    for (uint32_t bi = 0; bi < f.batches; ++bi) {
+        const uint32_t* w = (const uint32_t*)(base + RB_STRIDE * bi);
+        const unsigned long long* k = (const unsigned long long*)(base + RB_STRIDE * bi + CW_WORDS * 4);
+        uint32_t first = bi * f.blocks_per_batch;
+        uint32_t nb = std::min(f.blocks_per_batch, f.n_owned - first);
+        stats->rays_primary += (uint64_t)nb * f.bpix * f.spp;
+        for (uint32_t lvl = 0; lvl < f.max_depth; ++lvl) {
+            stats->rays_shadow += w[CW_NSHADOW + lvl];
+            stats->rays_reflection += w[CW_NCHAIN + lvl + 1];
+        }
+        stats->node_visits += k[0]; stats->box_tests += k[1]; stats->tri_tests += k[2]; stats->rays_march += k[3];
+        stats->wave_node_steps += k[4]; stats->wave_tri_steps += k[5]; stats->wave_outer_steps += k[6]; stats->wave_lane_steps += k[7];
+    }
+    float span = 0.0f;
+    for (size_t i = 0; i + 1 < f.ev_count; i += 2) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->events[f.ev_first + i], ctx->events[f.ev_first + i + 1]) == hipSuccess) {
+            if (f.ev_kind[i / 2] == 0) { stats->ms_trace += ms; stats->trace_launches++; }
+            else stats->ms_shade += ms;
+        }
+        if (hipEventElapsedTime(&ms, ctx->events[f.ev_first], ctx->events[f.ev_first + i + 1]) == hipSuccess) span = std::max(span, ms);
+    }
+    stats->blocks_rendered = f.blocks_done;
+    stats->ms_total = span;   // first kernel start to last kernel end of the frame, on the device clock
+}
 
 static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t max_depth, uint32_t flags, uint32_t shard,
                              uint32_t n_shards, uint8_t* strip_dev, size_t strip_bytes, hipStream_t st, uint32_t* ids_obj_dev,
@@ -599,14 +683,23 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     const uint64_t per_sample = 32 /*hits*/ + 4ull * LEVEL_PLANES * std::max(1u, max_depth) + 12 + 1 +
                                 4ull * L * std::max(1u, max_depth) + 32ull * L + 64;
     const uint64_t spb = (uint64_t)bpix * spp;
-    uint32_t lanes_want = 3, batches_per_lane = 2;
-    if (const char* e = std::getenv("TRR_LANES")) lanes_want = (uint32_t)std::min(trr_ctx::MAX_LANES, std::max(1, std::atoi(e)));
-    if (const char* e = std::getenv("TRR_BATCHES_PER_LANE")) batches_per_lane = (uint32_t)std::max(1, std::atoi(e));
-    const uint32_t lanes = interactive ? 1u : (uint32_t)std::min<uint64_t>(lanes_want, n_owned);
+    // Batch count: about 20 M samples per batch and at least two batches (measured on MI355X: smaller batches lose time in
+    // the ramp-up and tail of every persistent launch, larger ones leave nothing to overlap with); up to three lanes.
+    // TRR_LANES / TRR_BATCHES_PER_LANE override both (experiments).
+    const uint64_t total_samples = (uint64_t)n_owned * spb;
+    uint64_t want_batches = std::max<uint64_t>(2, (total_samples + (10ull << 20)) / (20ull << 20));
+    uint32_t lanes_want = (uint32_t)std::min<uint64_t>(3, want_batches);
+    const char* e_lanes = std::getenv("TRR_LANES");
+    const char* e_bpl = std::getenv("TRR_BATCHES_PER_LANE");
+    if (e_lanes || e_bpl) {
+        lanes_want = e_lanes ? (uint32_t)std::min(trr_ctx::MAX_LANES, std::max(1, std::atoi(e_lanes))) : 3u;
+        want_batches = (uint64_t)lanes_want * (e_bpl ? (uint32_t)std::max(1, std::atoi(e_bpl)) : 2u);
+    }
+    if (interactive) want_batches = 1;   // polled per batch: keep batches in order, as large as memory allows
+    want_batches = std::min<uint64_t>(want_batches, n_owned);
+    const uint32_t lanes = interactive ? 1u : (uint32_t)std::min<uint64_t>(lanes_want, want_batches);
     const uint64_t budget = (24ull << 30) / lanes;
     const uint64_t max_samples = std::min<uint64_t>(budget / per_sample, 1ull << 25);
-    // at least 2 batches per lane (when there are enough blocks) so that every lane's tail has something to hide behind
-    const uint64_t want_batches = interactive ? 1 : std::min<uint64_t>(n_owned, (uint64_t)batches_per_lane * lanes);
     uint32_t blocks_per_batch = (uint32_t)std::max<uint64_t>(
         1, std::min<uint64_t>((n_owned + want_batches - 1) / want_batches, max_samples / spb));
     const uint32_t cap = (uint32_t)(((uint64_t)blocks_per_batch * spb + 63) & ~63ull);
@@ -655,29 +748,28 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     fp.delta = delta; fp.max_depth = max_depth;
 
     const uint32_t n_batches = (n_owned + blocks_per_batch - 1) / blocks_per_batch;
-    // pinned readback area: per batch CW_WORDS words + 8 kernel counters
-    const size_t rb_stride = CW_WORDS * 4 + 64;
-    if (ctx->pinned_bytes < rb_stride * n_batches) {
-        HIPCHK(ctx, hipDeviceSynchronize());
-        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-        ctx->pinned = nullptr;
-        ctx->pinned_bytes = 0;
-        HIPCHK(ctx, hipHostMalloc(&ctx->pinned, rb_stride * n_batches, hipHostMallocDefault));
-        ctx->pinned_bytes = rb_stride * n_batches;
-    }
+    // statistics: per-launch events on the launch streams + one read-back of the queue / kernel counters per batch.
+    // TRR_FLAG_DEFER_STATS leaves both pending (no host synchronisation here); trr_collect_stats fills *stats later.
+    const bool defer = stats != nullptr && (flags & TRR_FLAG_DEFER_STATS) != 0;
+    const size_t rb_stride = RB_STRIDE;
+    int pinned_slot = -1;
+    if (stats && (rc = acquire_pinned(ctx, rb_stride * n_batches, &pinned_slot))) return rc;
+    char* pinned_base = stats ? (char*)ctx->pinned[pinned_slot].p : nullptr;
+    if (ctx->pending.empty()) ctx->events_used = 0;
+    const size_t ev_first = ctx->events_used;
     const bool timed = stats != nullptr;
     size_t n_events = 0;
     std::vector<uint8_t> ev_kind;   // 0 trace, 1 shade
     auto ev_begin = [&](uint8_t kind, hipStream_t s_) {
         if (!timed) return;
-        hipEvent_t e = get_event(ctx, n_events);
+        hipEvent_t e = get_event(ctx, ev_first + n_events);
         if (e) (void)hipEventRecord(e, s_);
         ++n_events;
         ev_kind.push_back(kind);
     };
     auto ev_end = [&](hipStream_t s_) {
         if (!timed) return;
-        hipEvent_t e = get_event(ctx, n_events);
+        hipEvent_t e = get_event(ctx, ev_first + n_events);
         if (e) (void)hipEventRecord(e, s_);
         ++n_events;
     };
@@ -758,7 +850,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
                        std::min<uint32_t>(aux_grid_max, (bp.n_pixels + 255) / 256), s_, fp, bp, rio);
         ev_end(s_);
         HIPCHK(ctx, hipGetLastError());
-        if (stats) HIPCHK(ctx, hipMemcpyAsync((char*)ctx->pinned + rb_stride * bi, w.counters.p, rb_stride, hipMemcpyDeviceToHost, s_));
+        if (stats) HIPCHK(ctx, hipMemcpyAsync(pinned_base + rb_stride * bi, w.counters.p, rb_stride, hipMemcpyDeviceToHost, s_));
         ++batches_run;
         blocks_done += bp.n_blocks;
         if (interactive) {
@@ -773,29 +865,25 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         }
     }
     if (stats) {
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        for (uint32_t bi = 0; bi < batches_run; ++bi) {
-            const uint32_t* w = (const uint32_t*)((char*)ctx->pinned + rb_stride * bi);
-            const unsigned long long* k = (const unsigned long long*)((char*)ctx->pinned + rb_stride * bi + CW_WORDS * 4);
-            uint32_t first = bi * blocks_per_batch;
-            uint32_t nb = std::min(blocks_per_batch, n_owned - first);
-            stats->rays_primary += (uint64_t)nb * bpix * spp;
-            for (uint32_t lvl = 0; lvl < max_depth; ++lvl) {
-                stats->rays_shadow += w[CW_NSHADOW + lvl];
-                stats->rays_reflection += w[CW_NCHAIN + lvl + 1];
+        trr_ctx::PendingStats f;
+        f.out = stats;
+        f.ev_first = ev_first; f.ev_count = n_events; f.ev_kind = ev_kind;
+        f.pinned_slot = pinned_slot;
+        f.batches = batches_run; f.blocks_per_batch = blocks_per_batch; f.n_owned = n_owned; f.bpix = bpix; f.spp = spp;
+        f.max_depth = max_depth; f.blocks_done = blocks_done;
+        f.caller_stream = st;
+        if (defer) {
+            ctx->events_used = ev_first + n_events;
+            ctx->pending.push_back(std::move(f));
+        } else {
+            hipError_t e_ = hipStreamSynchronize(st);
+            if (e_ == hipSuccess) {
+                finish_stats(ctx, f);
+                stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
             }
-            stats->node_visits += k[0]; stats->box_tests += k[1]; stats->tri_tests += k[2]; stats->rays_march += k[3];
-            stats->wave_node_steps += k[4]; stats->wave_tri_steps += k[5]; stats->wave_outer_steps += k[6]; stats->wave_lane_steps += k[7];
+            ctx->pinned[pinned_slot].in_use = false;
+            if (e_ != hipSuccess) return fail(ctx, TRR_ERR_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e_));
         }
-        for (size_t i = 0; i + 1 < n_events; i += 2) {
-            float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, ctx->events[i], ctx->events[i + 1]) == hipSuccess) {
-                if (ev_kind[i / 2] == 0) { stats->ms_trace += ms; stats->trace_launches++; }
-                else stats->ms_shade += ms;
-            }
-        }
-        stats->blocks_rendered = blocks_done;
-        stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     }
     if (result == TRR_ERR_CANCELLED) return fail(ctx, result, "render cancelled");
     return result;

@@ -162,6 +162,8 @@ DEV F3 primary_dir(const FrameParams& fp, uint32_t x, uint32_t y, uint32_t si) {
 // triangle.rs:53-85).  Persistent wavefronts pull rays from a device-side work counter; lanes whose ray
 // has finished are re-filled (ballot + one atomic per wavefront) once enough of them are idle.
 // ------------------------------------------------------------------------------------------------
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 constexpr int TRACE_THREADS = 256;
 constexpr uint8_t NLEV_PENDING = 0xFF;   // nlev value of a camera sample whose hit waits for k_setup (max_depth <= 255 keeps it free)
 #ifdef TRR_WAVES_PER_EU
@@ -170,7 +172,7 @@ constexpr uint8_t NLEV_PENDING = 0xFF;   // nlev value of a camera sample whose 
 #define TRR_OCCUPANCY_ATTR
 #endif
 #ifndef TRR_STACK_LDS
-#define TRR_STACK_LDS 16
+#define TRR_STACK_LDS 12
 #endif
 constexpr int STACK_LDS = TRR_STACK_LDS;       // per-lane (ref, tmin) entries kept in LDS
 constexpr int STACK_SPILL = 64 - STACK_LDS;     // further entries in a per-thread HBM spill area (rarely touched)
@@ -287,9 +289,14 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
     auto pop = [&]() -> uint32_t {
         while (sp > 0) {
             --sp;
-            uint2 e;   // (two explicit loads: a select between an LDS and a global address makes hipcc form a flat pointer)
+            uint2 e;
             if (sp < STACK_LDS) e = s_stack[sp * TRACE_THREADS + tid];
-            else e = my_spill[sp - STACK_LDS];
+            else {
+                e = my_spill[sp - STACK_LDS];
+                // an opaque use keeps the two branches apart (ds_read above, global_load here); merged into a select of
+                // addresses they become one flat_load, which cost 13 % of the frame time
+                asm volatile("" : "+v"(e.x), "+v"(e.y));
+            }
             if (!(__uint_as_float(e.y) > lim_n)) return e.x;
         }
         return REF_EMPTY;
@@ -469,6 +476,40 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
 
         if (node_step) {
             if (active && cur < REF_LEAF) {
+#ifdef TRR_PACKED
+                // Two children per instruction for the subtract and the multiply (v_pk_add_f32 / v_pk_mul_f32 issue at
+                // the rate of their scalar forms): the same IEEE operations on the same operands, so the same bits.
+                const float4v* nd = reinterpret_cast<const float4v*>(fp.nodes + cur);
+                float4v lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
+                uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
+                if (COUNT) {
+                    c_nodes++; c_boxes += 4;
+                    if (lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) c_wnode++;
+                }
+                const float2v oox = {oo.x, oo.x}, ooy = {oo.y, oo.y}, ooz = {oo.z, oo.z};
+                const float2v oix = {oi.x, oi.x}, oiy = {oi.y, oi.y}, oiz = {oi.z, oi.z};
+#define TRR_BOX2(TA, RA, TB, RB, LX, LY, LZ, HX, HY, HZ, CHA, CHB)                                         \
+    float TA, TB;                                                                                          \
+    uint32_t RA, RB;                                                                                       \
+    {                                                                                                      \
+        float2v ax = ((LX) - oox) * oix, bx = ((HX) - oox) * oix;                                          \
+        float2v ay = ((LY) - ooy) * oiy, by = ((HY) - ooy) * oiy;                                          \
+        float2v az = ((LZ) - ooz) * oiz, bz = ((HZ) - ooz) * oiz;                                          \
+        float tminA = rmax(rmax(rmin(ax.x, bx.x), rmin(ay.x, by.x)), rmin(az.x, bz.x));                    \
+        float tmaxA = rmin(rmin(rmax(ax.x, bx.x), rmax(ay.x, by.x)), rmax(az.x, bz.x));                    \
+        float tminB = rmax(rmax(rmin(ax.y, bx.y), rmin(ay.y, by.y)), rmin(az.y, bz.y));                    \
+        float tmaxB = rmin(rmin(rmax(ax.y, bx.y), rmax(ay.y, by.y)), rmax(az.y, bz.y));                    \
+        bool hitA = (tmaxA > rmax(tminA, 0.0f)) & !(tminA > lim_n);                                        \
+        bool hitB = (tmaxB > rmax(tminB, 0.0f)) & !(tminB > lim_n);                                        \
+        TA = hitA ? tminA : INFINITY;                                                                      \
+        RA = hitA ? (CHA) : REF_EMPTY;                                                                     \
+        TB = hitB ? tminB : INFINITY;                                                                      \
+        RB = hitB ? (CHB) : REF_EMPTY;                                                                     \
+    }
+                TRR_BOX2(t0, r0, t1, r1, lox.xy, loy.xy, loz.xy, hix.xy, hiy.xy, hiz.xy, ch.x, ch.y)
+                TRR_BOX2(t2, r2, t3, r3, lox.zw, loy.zw, loz.zw, hix.zw, hiy.zw, hiz.zw, ch.z, ch.w)
+#undef TRR_BOX2
+#else
                 const float4* nd = reinterpret_cast<const float4*>(fp.nodes + cur);
                 float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
                 uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
@@ -499,6 +540,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 TRR_BOX(t2, r2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
                 TRR_BOX(t3, r3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
 #undef TRR_BOX
+#endif
                 // sort the four (tmin, ref) pairs ascending: 5-comparator network of selects
 #define TRR_CSWAP(TI, RI, TJ, RJ)                                                  \
     {                                                                              \

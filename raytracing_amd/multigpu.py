@@ -78,44 +78,69 @@ def gather_strips_host(strip: np.ndarray, rank: int, world: int, group=None) -> 
 
 class ShardedRenderer:
     """One rank of a tile-sharded render.  ``raytracer`` is this rank's ``Raytracer`` (scene already uploaded to this
-    rank's GPU).  ``render()`` queues shard render -> gather -> (root) assemble on one side stream and returns
-    the frame tensor [h, w, 3] u8 on the root's GPU (None on the other ranks); nothing is synchronised."""
+    rank's GPU).  ``render()`` queues shard render -> gather -> (root) assemble and returns the frame tensor
+    [h, w, 3] u8 on the root's GPU (None on the other ranks); nothing is synchronised.
 
-    def __init__(self, raytracer, rank: int = 0, world: int = 1, group=None, use_dist: bool = None):
+    ``frames_in_flight`` (default 2) sets of buffers and render streams alternate, so that a sequence of frames
+    (an animation, a progressive render) keeps the GPU busy across frame boundaries: frame k+1's first block batches
+    start while frame k's last persistent trace kernels drain their few long rays.  A frame tensor returned by
+    ``render()`` is overwritten by the ``frames_in_flight``-th call after it.  The gathers and the assemble kernels
+    of all frames are issued on ONE stream, in frame order, so every rank issues its collectives in the same order."""
+
+    def __init__(self, raytracer, rank: int = 0, world: int = 1, group=None, use_dist: bool = None,
+                 frames_in_flight: int = 2):
         import torch
 
         self.rt = raytracer
         self.rank, self.world, self.group = int(rank), int(world), group
         self.use_dist = (self.world > 1) if use_dist is None else bool(use_dist)
+        if self.world > 1 and not self.use_dist:
+            raise ValueError("world > 1 needs the process group (use_dist): the root assembles the strips of every rank")
         self.device = torch.device("cuda", raytracer.ctx.device)
         self.sb = raytracer.strip_bytes(self.world)
-        self.strip = torch.zeros(self.sb, dtype=torch.uint8, device=self.device)
         self.is_root = self.rank == 0
-        if self.is_root:
-            self.strips = torch.zeros((self.world, self.sb), dtype=torch.uint8, device=self.device)
-            self.frame = torch.zeros((raytracer.height, raytracer.width, 3), dtype=torch.uint8, device=self.device)
-            self._views = [self.strips[i] for i in range(self.world)]
-        # A side stream of torch's: the library renders on it (torch's default stream has handle 0, which the C ABI
-        # reads as "the context's own stream"), the RCCL gather is ordered after the render because it is issued with
-        # this stream current, and so is the assemble kernel.
-        self.stream = torch.cuda.Stream(self.device)
+        self.n_slots = max(1, int(frames_in_flight))
+        self.slots = []
+        for _ in range(self.n_slots):
+            sl = {"strip": torch.zeros(self.sb, dtype=torch.uint8, device=self.device),
+                  # side streams of torch's: the library renders on them (torch's default stream has handle 0, which
+                  # the C ABI reads as "the context's own stream")
+                  "stream": torch.cuda.Stream(self.device),
+                  "rendered": torch.cuda.Event(), "consumed": torch.cuda.Event()}
+            if self.is_root:
+                sl["strips"] = torch.zeros((self.world, self.sb), dtype=torch.uint8, device=self.device)
+                sl["frame"] = torch.zeros((raytracer.height, raytracer.width, 3), dtype=torch.uint8, device=self.device)
+                sl["views"] = [sl["strips"][i] for i in range(self.world)]
+            self.slots.append(sl)
+        # gather + assemble of every frame, in frame order
+        self.comm_stream = torch.cuda.Stream(self.device)
+        self.frame_no = 0
         torch.cuda.synchronize(self.device)
 
-    def render(self, stats=None, counters: bool = False):
+    def render(self, stats=None, counters: bool = False, defer_stats: bool = False):
         import torch
         import torch.distributed as dist
 
-        with torch.cuda.stream(self.stream):
-            stream = self.stream.cuda_stream
-            self.rt.render_shard_device(self.rank, self.world, self.strip.data_ptr(), self.sb, stream=stream, stats=stats,
-                                        counters=counters)
+        sl = self.slots[self.frame_no % self.n_slots]
+        self.frame_no += 1
+        rs = sl["stream"]
+        rs.wait_event(sl["consumed"])          # the strip's previous contents have been gathered / assembled
+        with torch.cuda.stream(rs):
+            self.rt.render_shard_device(self.rank, self.world, sl["strip"].data_ptr(), self.sb, stream=rs.cuda_stream,
+                                        stats=stats, counters=counters, defer_stats=defer_stats)
+            sl["rendered"].record(rs)
+        cs = self.comm_stream
+        cs.wait_event(sl["rendered"])
+        frame = None
+        with torch.cuda.stream(cs):
             if self.use_dist:
                 # the single exchange of the path: finished RGB8 strips to the root (RCCL over xGMI with backend nccl)
-                dist.gather(self.strip, self._views if self.is_root else None, dst=0, group=self.group)
-                src = self.strips
+                dist.gather(sl["strip"], sl["views"] if self.is_root else None, dst=0, group=self.group)
+                src = sl["strips"] if self.is_root else None
             else:
-                src = self.strip
-            if not self.is_root:
-                return None
-            self.rt.assemble_device(self.world, src.data_ptr(), self.frame.data_ptr(), stream=stream)
-        return self.frame
+                src = sl["strip"]
+            if self.is_root:
+                self.rt.assemble_device(self.world, src.data_ptr(), sl["frame"].data_ptr(), stream=cs.cuda_stream)
+                frame = sl["frame"]
+            sl["consumed"].record(cs)
+        return frame

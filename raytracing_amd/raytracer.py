@@ -73,6 +73,10 @@ class Context:
     def handle(self):
         return self._h
 
+    def collect_stats(self):
+        """Waits for the frames rendered with ``defer_stats`` and fills their ``Stats``."""
+        N.check(N.lib().trr_collect_stats(self._h), self._h)
+
     def synchronize(self, stream: Optional[int] = None):
         N.check(N.lib().trr_synchronize(self._h, stream), self._h)
 
@@ -218,11 +222,13 @@ class Raytracer:
         return int(N.lib().trr_strip_bytes(self.width, self.height, int(n_shards)))
 
     def render_shard_device(self, shard: int, n_shards: int, strip_ptr: int, strip_bytes: int, stream: Optional[int] = None,
-                            counters: bool = False, stats: Optional[N.Stats] = None):
+                            counters: bool = False, stats: Optional[N.Stats] = None, defer_stats: bool = False):
         """This rank's blocks (block id % n_shards == shard) into a device strip; asynchronous on ``stream``
-        unless ``stats`` is given (statistics need the queue counters back)."""
+        unless ``stats`` is given without ``defer_stats`` (statistics need the queue counters back).  With
+        ``defer_stats`` the call stays asynchronous and ``stats`` is filled by ``Context.collect_stats()``."""
+        flags = (N.TRR_FLAG_COUNTERS if counters else 0) | (N.TRR_FLAG_DEFER_STATS if (defer_stats and stats is not None) else 0)
         rc = N.lib().trr_render_shard_device(self.ctx.handle, self._scene, self.delta, self.max_depth,
-                                             N.TRR_FLAG_COUNTERS if counters else 0, int(shard), int(n_shards),
+                                             flags, int(shard), int(n_shards),
                                              strip_ptr, int(strip_bytes), stream, None, None, None,
                                              C.addressof(stats) if stats is not None else None)
         if rc == N.TRR_ERR_RESOLUTION:

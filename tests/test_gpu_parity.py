@@ -276,3 +276,42 @@ def test_full_size_aa_batches_are_seamless(ctx):
     rt.ctx.synchronize()
     rt.close()
     assert np.array_equal(multigpu.assemble_host(strips.cpu().numpy(), 3840, 2160, n), whole)
+
+
+# ---- frames in flight / deferred statistics -----------------------------------------------------------------------------
+def test_sharded_renderer_pipelined_frames_are_identical(ctx):
+    """Two buffer sets alternate (frames_in_flight=2): every frame of a sequence equals the single-call frame, and the
+    statistics collected after the sequence equal the synchronous ones."""
+    import torch
+    sc = standin.parity_scene(320, 240, detail=12)
+    sc.settings.anti_aliasing, sc.settings.samples = True, 4
+    rt = Raytracer(sc, max_depth=4, context=ctx)
+    try:
+        want = rt.render_frame()["rgb"]
+        sync_stats = N.Stats()
+        sb = rt.strip_bytes(1)
+        tmp = torch.zeros(sb, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        rt.render_shard_device(0, 1, tmp.data_ptr(), sb, stats=sync_stats)
+        sr = multigpu.ShardedRenderer(rt, 0, 1, frames_in_flight=2)
+        stats = [N.Stats() for _ in range(5)]
+        frames = []
+        for k in range(5):
+            f = sr.render(stats=stats[k], defer_stats=True)
+            # a returned frame stays valid until the frames_in_flight-th call after it: copy it out in stream order
+            with torch.cuda.stream(sr.comm_stream):
+                frames.append(f.clone())
+        torch.cuda.synchronize()
+        ctx.collect_stats()
+        for k, f in enumerate(frames):
+            assert np.array_equal(f.cpu().numpy(), want), f"frame {k} of the pipelined sequence differs"
+        for st in stats:
+            assert st.rays() == sync_stats.rays() and st.rays_shadow == sync_stats.rays_shadow
+            assert st.trace_launches == sync_stats.trace_launches and st.blocks_rendered == 400
+            assert st.ms_trace > 0 and st.ms_total > 0
+    finally:
+        rt.close()
+
+
+def test_collect_stats_without_pending_frames_is_a_no_op(ctx):
+    ctx.collect_stats()
