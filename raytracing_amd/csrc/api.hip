@@ -459,6 +459,10 @@ int trr_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_ob
         depth_max = std::max(depth_max, br.max_depth);
         n_total += nt;
     }
+    // leaf references hold the first triangle slot in 29 bits, and the two highest 32-bit values are REF_EMPTY and the
+    // trace kernel's "idle lane" marker; node indices must stay below REF_LEAF
+    if (tris.size() >= (1ull << 29) - 1 || nodes.size() >= (1ull << 31))
+        return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: more than 2^29 - 2 triangles in one scene");
 
     trr_scene* sc = new trr_scene();
     sc->ctx = ctx;

@@ -162,8 +162,6 @@ DEV F3 primary_dir(const FrameParams& fp, uint32_t x, uint32_t y, uint32_t si) {
 // triangle.rs:53-85).  Persistent wavefronts pull rays from a device-side work counter; lanes whose ray
 // has finished are re-filled (ballot + one atomic per wavefront) once enough of them are idle.
 // ------------------------------------------------------------------------------------------------
-typedef float float2v __attribute__((ext_vector_type(2)));
-typedef float float4v __attribute__((ext_vector_type(4)));
 constexpr int TRACE_THREADS = 256;
 constexpr uint8_t NLEV_PENDING = 0xFF;   // nlev value of a camera sample whose hit waits for k_setup (max_depth <= 255 keeps it free)
 #ifdef TRR_WAVES_PER_EU
@@ -253,7 +251,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
     if ((blockIdx.x * (TRACE_THREADS / 64) + tid / 64) * 64u >= total) return;
 
     // ---- per-lane state (results go to memory as soon as a raycast ends; only the winner's slot/key stay live) ----
-    bool active = false;
+    // Per-lane booleans live in ONE register (bits of `fl`), and "this lane has no ray" is a value of `cur` (REF_IDLE):
+    // as separate bools they become SGPR lane masks that hipcc re-merges at every join of the loop (3 scalar
+    // instructions per bool and join, ~100 per iteration).
+    constexpr uint32_t F_FIRST = 1u, F_GHAVE = 2u, F_OHAVE = 4u, F_SKIPBOX = 8u;
+    constexpr uint32_t REF_IDLE = 0xFFFFFFFEu;           // never a leaf reference: slots stay below 2^29 - 1 (api.hip)
+    uint32_t fl = 0;
     bool exhausted = false, last_chunk = false;          // wave-uniform
     uint32_t w_next = 0, w_end = 0;                      // wave-uniform: this wavefront's claimed range of work items
     // chunk (guided self-scheduling): a fraction of what is left per wavefront, between one wavefront's worth and CHUNK_MAX
@@ -262,19 +265,16 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
     uint32_t chunk = max(64u, min(CHUNK_MAX, total / (n_waves * CHUNK_DIV)));
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 0);      // world ray (origin advances during the march)
     uint32_t r_out = 0, r_sample = 0, r_meta = 0;
-    bool first_cast = true;                      // no raycast of this ray has finished yet
     // one raycast (all objects)
     uint32_t obj_i = 0;
-    bool g_have = false;
     float g_key = 0, g_u = 0, g_v = 0, g_w = 0, t_lim = INFINITY;
     uint32_t g_slot = 0, g_obj = 0;
     // one object
     F3 oo = f3(0, 0, 0), od = f3(0, 0, 0), oi = f3(0, 0, 0);
     float len_d = 1.0f, lim_n = INFINITY, slack_abs = 0.0f;
-    bool o_have = false, skipbox = false;
     float o_key = 0;
     uint32_t o_slot = 0, o_tri = 0;
-    uint32_t cur = REF_EMPTY;
+    uint32_t cur = REF_IDLE;
     int sp = 0;
     unsigned long long c_nodes = 0, c_boxes = 0, c_tris = 0, c_march = 0;
     unsigned long long c_wnode = 0, c_wtri = 0, c_wouter = 0, c_lanes = 0;   // wave-level step counts (SIMD efficiency)
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
 
     for (;;) {
         // ---- re-fill idle lanes -------------------------------------------------------------
-        unsigned long long idle = __ballot(!active);
+        unsigned long long idle = __ballot(cur == REF_IDLE);
         if (idle != 0ull && !exhausted) {
             int nidle = __popcll(idle);
             if (nidle >= REFILL_MIN) {
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 uint32_t idx = w_next + rank;
                 w_next += take;
                 if (last_chunk && w_next >= w_end) exhausted = true;
-                if (!active && rank < take) {
+                if (cur == REF_IDLE && rank < take) {
                     if (RAYGEN) {
                         uint32_t pix = idx / fp.spp, si = idx - pix * fp.spp;
                         PixelPos pp = pixel_of(fp, bp, pix);
@@ -343,28 +343,25 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                         r_meta = __float_as_uint(b.w);
                         r_out = idx - n_shadow;   // meaningful for chain rays only
                     }
-                    active = true;
-                    first_cast = true;
+                    fl = F_FIRST;          // no raycast of this ray has finished yet; no hit of any kind
                     obj_i = 0xFFFFFFFFu;   // "before the first object"
-                    g_have = false;
                     t_lim = INFINITY;
-                    o_have = false;
                     cur = REF_EMPTY;
                     sp = 0;
                 }
             }
         }
-        if (__ballot(active) == 0ull) break;
+        if (__ballot(cur != REF_IDLE) == 0ull) break;
         if (COUNT) {
             if (lane == 0) c_wouter++;
-            if (active) c_lanes++;
+            if (cur != REF_IDLE) c_lanes++;
         }
 
         // ---- transition: object finished / raycast finished / ray finished ----------------------
-        if (active && cur == REF_EMPTY) {
+        if (cur == REF_EMPTY) {
             // object.rs:206-219: best candidate of the object -> world space, then mod.rs:50 ranks objects by
             // |point_world - ray.origin| (first object wins ties: strict <, NaN greatest)
-            if (o_have) {
+            if (fl & F_OHAVE) {
                 const ObjRec* ob = fp.objs + obj_i;
                 const float4* tp = reinterpret_cast<const float4*>(fp.tris + o_slot);
                 float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
@@ -374,18 +371,18 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 F3 pw = xform_point(ob->fwd, h.point);
                 float key = norm(pw - ro);
                 bool better;
-                if (!g_have) better = true;
+                if (!(fl & F_GHAVE)) better = true;
                 else if (is_nan(key)) better = false;
                 else if (is_nan(g_key)) better = true;
                 else better = key < g_key;
                 if (better) {
-                    g_have = true; g_key = key; g_slot = o_slot; g_obj = obj_i;
+                    fl |= F_GHAVE; g_key = key; g_slot = o_slot; g_obj = obj_i;
                     g_u = h.u; g_v = h.v; g_w = h.w;
                     // later objects only need boxes nearer than this hit (ray parameter + slack)
                     float th = sqrtf(h.key) / len_d;
                     if (th == th) t_lim = th * (1.0f + PRUNE_REL);
                 }
-                o_have = false;
+                fl &= ~F_OHAVE;
             }
             ++obj_i;
             if (obj_i >= fp.n_objs) {
@@ -393,7 +390,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 // so each finished raycast with a hit overwrites the ray's result record
                 const bool is_shadow = !RAYGEN && (r_meta & 0x100u) != 0u;
                 bool again = false;
-                if (g_have) {
+                const bool first_cast = (fl & F_FIRST) != 0u;
+                if (fl & F_GHAVE) {
                     const float4 q3 = reinterpret_cast<const float4*>(fp.tris + g_slot)[3];
                     const uint32_t tri_id = __float_as_uint(q3.x);
                     const int32_t mat = (int32_t)__float_as_uint(q3.y);
@@ -438,16 +436,15 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                         io.first_tri[r_sample] = 0xFFFFFFFFu;
                     }
                 }
-                first_cast = false;
+                fl &= ~(F_FIRST | F_GHAVE);
                 if (again) {
                     obj_i = 0;
-                    g_have = false;
                     t_lim = INFINITY;
                 } else {
-                    active = false;
+                    cur = REF_IDLE;
                 }
             }
-            if (active) {
+            if (cur != REF_IDLE) {
                 // object.rs:186-195: ray into object space (direction NOT renormalised), bvh::Ray::new
                 // normalises its own copy and keeps 1/direction [crate]
                 const ObjRec* ob = fp.objs + obj_i;
@@ -459,8 +456,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 slack_abs = ob->slack_abs;
                 lim_n = t_lim * len_d + slack_abs;
                 if (!(lim_n == lim_n)) lim_n = INFINITY;
-                skipbox = (ob->flags & 1u) != 0u;
-                o_have = false;
+                fl = (fl & ~(F_OHAVE | F_SKIPBOX)) | ((ob->flags & 1u) ? F_SKIPBOX : 0u);
                 cur = ob->root;
                 sp = 0;
             }
@@ -470,46 +466,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
         // visits it, or every lane that stands on a leaf tests ONE of its triangles.  The kind with more waiting lanes
         // runs (node steps weighted by NODE_BIAS/8); the other lanes keep their state for a later iteration.  A step
         // costs the same whether 1 or 64 lanes need it, so this keeps the SIMD lanes of divergent rays busy.
-        const unsigned long long m_inner = __ballot(active && cur < REF_LEAF);
-        const unsigned long long m_leaf = __ballot(active && cur >= REF_LEAF && cur != REF_EMPTY);
+        const unsigned long long m_inner = __ballot(cur < REF_LEAF);
+        const unsigned long long m_leaf = __ballot(cur >= REF_LEAF && cur < REF_IDLE);
         const bool node_step = m_inner != 0ull && (__popcll(m_inner) * NODE_BIAS >= __popcll(m_leaf) * 8);
 
         if (node_step) {
-            if (active && cur < REF_LEAF) {
-#ifdef TRR_PACKED
-                // Two children per instruction for the subtract and the multiply (v_pk_add_f32 / v_pk_mul_f32 issue at
-                // the rate of their scalar forms): the same IEEE operations on the same operands, so the same bits.
-                const float4v* nd = reinterpret_cast<const float4v*>(fp.nodes + cur);
-                float4v lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
-                uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
-                if (COUNT) {
-                    c_nodes++; c_boxes += 4;
-                    if (lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) c_wnode++;
-                }
-                const float2v oox = {oo.x, oo.x}, ooy = {oo.y, oo.y}, ooz = {oo.z, oo.z};
-                const float2v oix = {oi.x, oi.x}, oiy = {oi.y, oi.y}, oiz = {oi.z, oi.z};
-#define TRR_BOX2(TA, RA, TB, RB, LX, LY, LZ, HX, HY, HZ, CHA, CHB)                                         \
-    float TA, TB;                                                                                          \
-    uint32_t RA, RB;                                                                                       \
-    {                                                                                                      \
-        float2v ax = ((LX) - oox) * oix, bx = ((HX) - oox) * oix;                                          \
-        float2v ay = ((LY) - ooy) * oiy, by = ((HY) - ooy) * oiy;                                          \
-        float2v az = ((LZ) - ooz) * oiz, bz = ((HZ) - ooz) * oiz;                                          \
-        float tminA = rmax(rmax(rmin(ax.x, bx.x), rmin(ay.x, by.x)), rmin(az.x, bz.x));                    \
-        float tmaxA = rmin(rmin(rmax(ax.x, bx.x), rmax(ay.x, by.x)), rmax(az.x, bz.x));                    \
-        float tminB = rmax(rmax(rmin(ax.y, bx.y), rmin(ay.y, by.y)), rmin(az.y, bz.y));                    \
-        float tmaxB = rmin(rmin(rmax(ax.y, bx.y), rmax(ay.y, by.y)), rmax(az.y, bz.y));                    \
-        bool hitA = (tmaxA > rmax(tminA, 0.0f)) & !(tminA > lim_n);                                        \
-        bool hitB = (tmaxB > rmax(tminB, 0.0f)) & !(tminB > lim_n);                                        \
-        TA = hitA ? tminA : INFINITY;                                                                      \
-        RA = hitA ? (CHA) : REF_EMPTY;                                                                     \
-        TB = hitB ? tminB : INFINITY;                                                                      \
-        RB = hitB ? (CHB) : REF_EMPTY;                                                                     \
-    }
-                TRR_BOX2(t0, r0, t1, r1, lox.xy, loy.xy, loz.xy, hix.xy, hiy.xy, hiz.xy, ch.x, ch.y)
-                TRR_BOX2(t2, r2, t3, r3, lox.zw, loy.zw, loz.zw, hix.zw, hiy.zw, hiz.zw, ch.z, ch.w)
-#undef TRR_BOX2
-#else
+            if (cur < REF_LEAF) {
                 const float4* nd = reinterpret_cast<const float4*>(fp.nodes + cur);
                 float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
                 uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
@@ -540,7 +502,6 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 TRR_BOX(t2, r2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
                 TRR_BOX(t3, r3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
 #undef TRR_BOX
-#endif
                 // sort the four (tmin, ref) pairs ascending: 5-comparator network of selects
 #define TRR_CSWAP(TI, RI, TJ, RJ)                                                  \
     {                                                                              \
@@ -569,7 +530,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
             }
         } else if (m_leaf != 0ull) {
             // ---- leaf: own-box test + exact test of the leaf's first remaining triangle ------------------------
-            if (active && cur >= REF_LEAF && cur != REF_EMPTY) {
+            if (cur >= REF_LEAF && cur < REF_IDLE) {
                 const uint32_t slot = (cur & 0x7FFFFFFFu) >> 2;
                 const float4* tp = reinterpret_cast<const float4*>(fp.tris + slot);
                 float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
@@ -578,7 +539,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                     if (lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) c_wtri++;
                 }
                 bool cand = true;
-                if (!skipbox) {
+                if (!(fl & F_SKIPBOX)) {
                     // triangle.rs:88-95 box (empty.grow(a).grow(b).grow(c + 1e-4)) + [crate] slab test
                     F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x);
                     F3 c2 = f3(c.x + 0.0001f, c.y + 0.0001f, c.z + 0.0001f);
@@ -597,8 +558,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                     TriHit h;
                     if (tri_test(q0, q1, q2, q3.z, oo, od, fp.delta, h)) {
                         uint32_t tri_id = __float_as_uint(q3.x);
-                        if (candidate_better(o_have, h.key, tri_id, o_key, o_tri)) {
-                            o_have = true; o_key = h.key; o_slot = slot; o_tri = tri_id;
+                        if (candidate_better((fl & F_OHAVE) != 0u, h.key, tri_id, o_key, o_tri)) {
+                            fl |= F_OHAVE; o_key = h.key; o_slot = slot; o_tri = tri_id;
                             float dist = sqrtf(h.key);
                             if (dist == dist) lim_n = rmin(lim_n, dist * (1.0f + PRUNE_REL) + slack_abs);
                         }
