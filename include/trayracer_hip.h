@@ -122,6 +122,8 @@ typedef struct trr_stats {
     uint64_t wave_tri_steps;       /* triangle-slot iterations of the leaf loop; box_tests-4*node_visits over 64*this */
     uint64_t wave_outer_steps;     /* outer (refill / transition / descend / leaf) iterations */
     uint64_t wave_lane_steps;      /* sum over outer iterations of lanes that still carry a ray */
+    uint64_t wave_trans_steps;     /* executions of the transition block (ray start / object change / ray end) per wavefront */
+    uint64_t trans_lanes;          /* lanes that took part in them */
 } trr_stats;
 
 typedef void (*trr_progress_cb)(void* user, uint32_t blocks_done, uint32_t blocks_total);

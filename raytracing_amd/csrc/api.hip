@@ -599,7 +599,7 @@ static hipEvent_t get_event(trr_ctx* ctx, size_t i) {
 // [CW_NSHADOW + lvl] shadow rays emitted at level lvl, [CW_NCHAIN + lvl] chain rays entering level lvl;
 // the 64-bit kernel counters follow at byte offset CW_WORDS*4.
 enum { CW_WORK = 0, CW_NSHADOW = 288, CW_NCHAIN = 576, CW_WORDS = 1024 };
-static constexpr size_t RB_STRIDE = CW_WORDS * 4 + 64;   // per batch: queue counters + 8 kernel counters
+static constexpr size_t RB_STRIDE = CW_WORDS * 4 + 96;   // per batch: queue counters + up to 12 kernel counters
 
 static int acquire_pinned(trr_ctx* ctx, size_t bytes, int* slot) {
     for (size_t i = 0; i < ctx->pinned.size(); ++i)
@@ -633,6 +633,7 @@ static void finish_stats(trr_ctx* ctx, const trr_ctx::PendingStats& f) {
         }
         stats->node_visits += k[0]; stats->box_tests += k[1]; stats->tri_tests += k[2]; stats->rays_march += k[3];
         stats->wave_node_steps += k[4]; stats->wave_tri_steps += k[5]; stats->wave_outer_steps += k[6]; stats->wave_lane_steps += k[7];
+        stats->wave_trans_steps += k[8]; stats->trans_lanes += k[9];
     }
     float span = 0.0f;
     for (size_t i = 0; i + 1 < f.ev_count; i += 2) {
@@ -720,7 +721,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
             (rc = ensure(ctx, w.occ, (size_t)cap * 4 * std::max(1u, L) * D)) ||
             (rc = ensure(ctx, w.shadow_q, (size_t)cap * sizeof(RayRec) * std::max(1u, L))) ||
             (rc = ensure(ctx, w.chain_q[0], (size_t)cap * sizeof(RayRec))) ||
-            (rc = ensure(ctx, w.chain_q[1], (size_t)cap * sizeof(RayRec))) || (rc = ensure(ctx, w.counters, CW_WORDS * 4 + 64)) ||
+            (rc = ensure(ctx, w.chain_q[1], (size_t)cap * sizeof(RayRec))) || (rc = ensure(ctx, w.counters, RB_STRIDE)) ||
             (rc = ensure(ctx, w.spill, trace_spill_bytes(trace_grid))))
             return rc;
     }
@@ -801,7 +802,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         bp.n_pixels = bp.n_blocks * bpix;
         bp.n_samples = bp.n_pixels * spp;
         bp.cap = cap;
-        HIPCHK(ctx, hipMemsetAsync(w.counters.p, 0, CW_WORDS * 4 + 64, s_));
+        HIPCHK(ctx, hipMemsetAsync(w.counters.p, 0, RB_STRIDE, s_));
         const uint32_t aux_grid = std::min<uint32_t>(aux_grid_max, (bp.n_samples + 255) / 256);
 
         TraceIO tio{};

@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
     uint32_t cur = REF_IDLE;
     int sp = 0;
     unsigned long long c_nodes = 0, c_boxes = 0, c_tris = 0, c_march = 0;
-    unsigned long long c_wnode = 0, c_wtri = 0, c_wouter = 0, c_lanes = 0;   // wave-level step counts (SIMD efficiency)
+    unsigned long long c_wnode = 0, c_wtri = 0, c_wouter = 0, c_lanes = 0, c_wtrans = 0, c_ltrans = 0;   // wave-level step counts (SIMD efficiency)
 
     auto push = [&](uint32_t ref, float tmin) {
         uint2 e = make_uint2(ref, __float_as_uint(tmin));
@@ -358,9 +358,21 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
         }
 
         // ---- transition: object finished / raycast finished / ray finished ----------------------
+        if (COUNT) {
+            unsigned long long tm = __ballot(cur == REF_EMPTY);
+            if (tm != 0ull && lane == (uint32_t)__ffsll((long long)tm) - 1u) c_wtrans++;
+            if (cur == REF_EMPTY) c_ltrans++;
+        }
         if (cur == REF_EMPTY) {
             // object.rs:206-219: best candidate of the object -> world space, then mod.rs:50 ranks objects by
             // |point_world - ray.origin| (first object wins ties: strict <, NaN greatest)
+            // (a shadow ray only reports the occluder's material: with a single object there is nothing to rank, so the
+            // winner of the object is the winner of the raycast and its barycentrics are never read)
+            const bool rank_free = !RAYGEN && fp.n_objs == 1u && (r_meta & 0x100u) != 0u;
+            if ((fl & F_OHAVE) && rank_free) {
+                fl = (fl | F_GHAVE) & ~F_OHAVE;
+                g_slot = o_slot;
+            }
             if (fl & F_OHAVE) {
                 const ObjRec* ob = fp.objs + obj_i;
                 const float4* tp = reinterpret_cast<const float4*>(fp.tris + o_slot);
@@ -419,12 +431,9 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                         uint32_t level = r_meta & 0xFFu, light = r_meta >> 16;
                         io.occ[((size_t)level * fp.n_lights + light) * bp.cap + r_sample] = -1;
                     } else if (RAYGEN) {
-                        // mod.rs:119: a camera ray that hits nothing is skybox(ray.direction); finished here, no hit
-                        // record is written and k_setup skips the sample
-                        F3 c = skybox(fp, rd);
-                        io.term[0 * (size_t)bp.cap + r_meta] = c.x;
-                        io.term[1 * (size_t)bp.cap + r_meta] = c.y;
-                        io.term[2 * (size_t)bp.cap + r_meta] = c.z;
+                        // mod.rs:119: a camera ray that hits nothing is skybox(ray.direction).  Only the fact is recorded
+                        // here (no hit record); k_setup<LEVEL0> evaluates the sky for these samples with full wavefronts
+                        // instead of the few lanes that end their ray in this iteration
                         io.nlev[r_meta] = 0;
                     } else {
                         float4* dst = reinterpret_cast<float4*>(io.hits + r_out);
@@ -582,6 +591,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
             c_wtri += __shfl_down(c_wtri, off);
             c_wouter += __shfl_down(c_wouter, off);
             c_lanes += __shfl_down(c_lanes, off);
+            c_wtrans += __shfl_down(c_wtrans, off);
+            c_ltrans += __shfl_down(c_ltrans, off);
         }
         if (lane == 0) {
             atomicAdd(io.counters + 0, c_nodes);
@@ -592,6 +603,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
             atomicAdd(io.counters + 5, c_wtri);
             atomicAdd(io.counters + 6, c_wouter);
             atomicAdd(io.counters + 7, c_lanes);
+            atomicAdd(io.counters + 8, c_wtrans);
+            atomicAdd(io.counters + 9, c_ltrans);
         }
     }
 }
@@ -622,7 +635,16 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
         bool hit = false, reflective = false, spawn = false;
         F3 P = f3(0, 0, 0), N = f3(0, 0, 0), D = f3(0, 0, 0);
         uint32_t sample = 0;
-        if (LEVEL0 && valid && io.nlev[i] != NLEV_PENDING) valid = false;   // a miss, finished by k_trace<RAYGEN>
+        if (LEVEL0 && valid && io.nlev[i] != NLEV_PENDING) {
+            // a camera ray that missed everything (k_trace<RAYGEN> left nlev == 0): mod.rs:119, skybox(ray.direction)
+            uint32_t pix = i / fp.spp, si = i - pix * fp.spp;
+            PixelPos pp = pixel_of(fp, bp, pix);
+            F3 c = skybox(fp, primary_dir(fp, pp.x, pp.y, si));
+            io.term[0 * (size_t)cap + i] = c.x;
+            io.term[1 * (size_t)cap + i] = c.y;
+            io.term[2 * (size_t)cap + i] = c.z;
+            valid = false;
+        }
         if (valid) {
             if (LEVEL0) {
                 sample = i;
