@@ -66,6 +66,7 @@ struct trr_ctx {
     hipEvent_t fork = nullptr;
     DevBuf strip, frame, ids_obj, ids_tri;
     std::vector<hipEvent_t> events;
+    uint64_t budget_total = 0;           // bytes the work sets of all lanes may take together (set at the first render)
     size_t events_used = 0;              // events handed to frames whose statistics are still pending
     // pinned read-back chunks (queue counters + kernel counters of one frame each), reused once collected
     struct Pinned {
@@ -688,22 +689,35 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     const uint64_t per_sample = 32 /*hits*/ + 4ull * LEVEL_PLANES * std::max(1u, max_depth) + 12 + 1 +
                                 4ull * L * std::max(1u, max_depth) + 32ull * L + 64;
     const uint64_t spb = (uint64_t)bpix * spp;
-    // Batch count: about 20 M samples per batch and at least two batches (measured on MI355X: smaller batches lose time in
-    // the ramp-up and tail of every persistent launch, larger ones leave nothing to overlap with); up to three lanes.
-    // TRR_LANES / TRR_BATCHES_PER_LANE override both (experiments).
+    // Batch count (measured on MI355X, scratch sweeps of round 1): few, large batches -- every persistent launch pays a
+    // ramp-up and a tail of fixed length -- but at least two, on two lanes, so that one batch's tails and small deep-level
+    // launches overlap the other's bulk; three lanes once there are four or more batches.  An odd batch per lane keeps
+    // the lanes out of lock-step.  TRR_LANES / TRR_BATCHES_PER_LANE / TRR_BATCHES override (experiments).
     const uint64_t total_samples = (uint64_t)n_owned * spb;
-    uint64_t want_batches = std::max<uint64_t>(2, (total_samples + (10ull << 20)) / (20ull << 20));
-    uint32_t lanes_want = (uint32_t)std::min<uint64_t>(3, want_batches);
+    uint64_t want_batches = std::max<uint64_t>(2, (total_samples + (1ull << 25) - 1) >> 25);
+    uint32_t lanes_want = want_batches >= 4 ? 3u : 2u;
     const char* e_lanes = std::getenv("TRR_LANES");
     const char* e_bpl = std::getenv("TRR_BATCHES_PER_LANE");
     if (e_lanes || e_bpl) {
         lanes_want = e_lanes ? (uint32_t)std::min(trr_ctx::MAX_LANES, std::max(1, std::atoi(e_lanes))) : 3u;
         want_batches = (uint64_t)lanes_want * (e_bpl ? (uint32_t)std::max(1, std::atoi(e_bpl)) : 2u);
     }
+    if (const char* e = std::getenv("TRR_BATCHES")) {
+        want_batches = (uint64_t)std::max(1, std::atoi(e));
+        lanes_want = e_lanes ? lanes_want : (uint32_t)std::min<uint64_t>(3, want_batches);
+    }
     if (interactive) want_batches = 1;   // polled per batch: keep batches in order, as large as memory allows
     want_batches = std::min<uint64_t>(want_batches, n_owned);
     const uint32_t lanes = interactive ? 1u : (uint32_t)std::min<uint64_t>(lanes_want, want_batches);
-    const uint64_t budget = (24ull << 30) / lanes;
+    // work-buffer budget: a third of the device memory that is free now, at most 96 GB (MI355X: 288 GB HBM3E per GPU)
+    if (ctx->budget_total == 0) {   // asked once per context: the query is an ioctl
+        ctx->budget_total = 24ull << 30;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            ctx->budget_total = std::max<uint64_t>(1ull << 30, std::min<uint64_t>(96ull << 30, (uint64_t)free_b / 3));
+    }
+    const uint64_t budget_total = ctx->budget_total;
+    const uint64_t budget = budget_total / lanes;
     const uint64_t max_samples = std::min<uint64_t>(budget / per_sample, 1ull << 25);
     uint32_t blocks_per_batch = (uint32_t)std::max<uint64_t>(
         1, std::min<uint64_t>((n_owned + want_batches - 1) / want_batches, max_samples / spb));
