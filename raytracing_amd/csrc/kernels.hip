@@ -186,6 +186,9 @@ constexpr float PRUNE_REL = TRR_PRUNE_REL;
 #define TRR_NODE_BIAS 8
 #endif
 constexpr int NODE_BIAS = TRR_NODE_BIAS;
+#ifndef TRR_TRIS_PER_STEP
+#define TRR_TRIS_PER_STEP 2   // 2: -4 % frame time against 1 (fewer, fatter leaf iterations); whole leaves cost a wave of occupancy
+#endif
 #ifndef TRR_CHUNK_DIV
 #define TRR_CHUNK_DIV 8
 #endif
@@ -538,44 +541,60 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 cur = (r0 != REF_EMPTY) ? r0 : pop();
             }
         } else if (m_leaf != 0ull) {
-            // ---- leaf: own-box test + exact test of the leaf's first remaining triangle ------------------------
+            // ---- leaf: own-box test + exact test of the leaf's next TRR_TRIS_PER_STEP remaining triangles ------------
             if (cur >= REF_LEAF && cur < REF_IDLE) {
                 const uint32_t slot = (cur & 0x7FFFFFFFu) >> 2;
-                const float4* tp = reinterpret_cast<const float4*>(fp.tris + slot);
-                float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
                 if (COUNT) {
-                    c_boxes++;
                     if (lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) c_wtri++;
                 }
-                bool cand = true;
-                if (!(fl & F_SKIPBOX)) {
-                    // triangle.rs:88-95 box (empty.grow(a).grow(b).grow(c + 1e-4)) + [crate] slab test
-                    F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x);
-                    F3 c2 = f3(c.x + 0.0001f, c.y + 0.0001f, c.z + 0.0001f);
-                    F3 lo = f3(rmin(rmin(a.x, b.x), c2.x), rmin(rmin(a.y, b.y), c2.y), rmin(rmin(a.z, b.z), c2.z));
-                    F3 hi = f3(rmax(rmax(a.x, b.x), c2.x), rmax(rmax(a.y, b.y), c2.y), rmax(rmax(a.z, b.z), c2.z));
-                    float ax = (lo.x - oo.x) * oi.x, bx = (hi.x - oo.x) * oi.x;
-                    float ay = (lo.y - oo.y) * oi.y, by = (hi.y - oo.y) * oi.y;
-                    float az = (lo.z - oo.z) * oi.z, bz = (hi.z - oo.z) * oi.z;
-                    float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));
-                    float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));
-                    // the second condition: cannot beat the current best (slack keeps this conservative)
-                    cand = (tmax > rmax(tmin, 0.0f)) && !(tmin > lim_n);
-                }
-                if (cand) {
-                    if (COUNT) c_tris++;
-                    TriHit h;
-                    if (tri_test(q0, q1, q2, q3.z, oo, od, fp.delta, h)) {
-                        uint32_t tri_id = __float_as_uint(q3.x);
-                        if (candidate_better((fl & F_OHAVE) != 0u, h.key, tri_id, o_key, o_tri)) {
-                            fl |= F_OHAVE; o_key = h.key; o_slot = slot; o_tri = tri_id;
-                            float dist = sqrtf(h.key);
-                            if (dist == dist) lim_n = rmin(lim_n, dist * (1.0f + PRUNE_REL) + slack_abs);
+                // one triangle: triangle.rs:88-95 box (empty.grow(a).grow(b).grow(c + 1e-4)) + [crate] slab test, then the
+                // exact test; candidates are ranked by (key, triangle id), so the order of the tests does not matter
+                auto test_one = [&](uint32_t sl, float4 q0, float4 q1, float4 q2, float4 q3) {
+                    if (COUNT) c_boxes++;
+                    bool cand = true;
+                    if (!(fl & F_SKIPBOX)) {
+                        F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x);
+                        F3 c2 = f3(c.x + 0.0001f, c.y + 0.0001f, c.z + 0.0001f);
+                        F3 lo = f3(rmin(rmin(a.x, b.x), c2.x), rmin(rmin(a.y, b.y), c2.y), rmin(rmin(a.z, b.z), c2.z));
+                        F3 hi = f3(rmax(rmax(a.x, b.x), c2.x), rmax(rmax(a.y, b.y), c2.y), rmax(rmax(a.z, b.z), c2.z));
+                        float ax = (lo.x - oo.x) * oi.x, bx = (hi.x - oo.x) * oi.x;
+                        float ay = (lo.y - oo.y) * oi.y, by = (hi.y - oo.y) * oi.y;
+                        float az = (lo.z - oo.z) * oi.z, bz = (hi.z - oo.z) * oi.z;
+                        float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));
+                        float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));
+                        // the second condition: cannot beat the current best (slack keeps this conservative)
+                        cand = (tmax > rmax(tmin, 0.0f)) && !(tmin > lim_n);
+                    }
+                    if (cand) {
+                        if (COUNT) c_tris++;
+                        TriHit h;
+                        if (tri_test(q0, q1, q2, q3.z, oo, od, fp.delta, h)) {
+                            uint32_t tri_id = __float_as_uint(q3.x);
+                            if (candidate_better((fl & F_OHAVE) != 0u, h.key, tri_id, o_key, o_tri)) {
+                                fl |= F_OHAVE; o_key = h.key; o_slot = sl; o_tri = tri_id;
+                                float dist = sqrtf(h.key);
+                                if (dist == dist) lim_n = rmin(lim_n, dist * (1.0f + PRUNE_REL) + slack_abs);
+                            }
                         }
                     }
-                }
+                };
+                const float4* tp = reinterpret_cast<const float4*>(fp.tris + slot);
+#if TRR_TRIS_PER_STEP >= 2
+                // both records are requested before the first is used: the second one's latency hides behind the first test
+                uint32_t sl = slot;
+                const bool two = (cur & 3u) != 0u;
+                const float4* tq = two ? tp + 4 : tp;
+                float4 a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3];
+                float4 b0 = tq[0], b1 = tq[1], b2 = tq[2], b3 = tq[3];
+                test_one(sl, a0, a1, a2, a3);
+                if (two) test_one(sl + 1u, b0, b1, b2, b3);
+                // ref = LEAF | first << 2 | count-1: two triangles consumed -> first+2, count-2
+                cur = ((cur & 3u) >= 2u) ? cur + 6u : pop();
+#else
+                test_one(slot, tp[0], tp[1], tp[2], tp[3]);
                 // next triangle of the leaf (ref = LEAF | first << 2 | count-1  ->  first+1, count-2), else pop
                 cur = (cur & 3u) ? cur + 3u : pop();
+#endif
             }
         }
     }
