@@ -656,9 +656,12 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
         uint32_t sample = 0;
         if (LEVEL0 && valid && io.nlev[i] != NLEV_PENDING) {
             // a camera ray that missed everything (k_trace<RAYGEN> left nlev == 0): mod.rs:119, skybox(ray.direction)
-            uint32_t pix = i / fp.spp, si = i - pix * fp.spp;
-            PixelPos pp = pixel_of(fp, bp, pix);
-            F3 c = skybox(fp, primary_dir(fp, pp.x, pp.y, si));
+            F3 c = f3(fp.sky_color[0], fp.sky_color[1], fp.sky_color[2]);
+            if (fp.sky != nullptr) {   // (a constant sky needs no direction)
+                uint32_t pix = i / fp.spp, si = i - pix * fp.spp;
+                PixelPos pp = pixel_of(fp, bp, pix);
+                c = skybox(fp, primary_dir(fp, pp.x, pp.y, si));
+            }
             io.term[0 * (size_t)cap + i] = c.x;
             io.term[1 * (size_t)cap + i] = c.y;
             io.term[2 * (size_t)cap + i] = c.z;
@@ -853,15 +856,45 @@ __global__ void __launch_bounds__(256) k_resolve_samples(FrameParams fp, BatchPa
 // (render.rs:134-140), store into the shard's strip.
 __global__ void __launch_bounds__(256) k_resolve_pixels(FrameParams fp, BatchParams bp, ResolveIO io) {
     const size_t cap = bp.cap;
+    const uint32_t spp = fp.spp;
+    if (spp >= 2u && spp <= 64u && (spp & (spp - 1u)) == 0u) {
+        // One lane per SAMPLE (coalesced reads of the three planes), spp consecutive lanes per pixel; every lane of a
+        // group adds the group's values in ascending sample order -- the order of the sequential sum -- and the first
+        // lane writes the pixel.  Whole wavefronts iterate together (the shuffles need every lane present).
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t base = lane & ~(spp - 1u);
+        const uint32_t stride = gridDim.x * blockDim.x;
+        const uint32_t rounds = (bp.n_samples + stride - 1) / stride;
+        for (uint32_t it = 0; it < rounds; ++it) {
+            uint32_t s = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+            bool valid = s < bp.n_samples;   // n_samples is a multiple of spp: a group is valid or invalid as a whole
+            F3 v = f3(0.0f, 0.0f, 0.0f);
+            if (valid) v = f3(io.term[s], io.term[cap + s], io.term[2 * cap + s]);
+            F3 sum = f3(0.0f, 0.0f, 0.0f);
+            for (uint32_t j = 0; j < spp; ++j) {
+                F3 c = f3(__shfl(v.x, (int)(base + j)), __shfl(v.y, (int)(base + j)), __shfl(v.z, (int)(base + j)));
+                sum = sum + c;
+            }
+            if (valid && lane == base) {
+                F3 color = fp.aa ? unscale(sum, (float)spp) : v;   // mod.rs:248-249 (spp > 1 implies aa)
+                PixelPos pp = pixel_of(fp, bp, s / spp);
+                uint8_t* o = io.strip + (size_t)pp.strip_off * 3;
+                o[0] = quantize(color.x);
+                o[1] = quantize(color.y);
+                o[2] = quantize(color.z);
+            }
+        }
+        return;
+    }
     for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < bp.n_pixels; pix += gridDim.x * blockDim.x) {
         F3 sum = f3(0.0f, 0.0f, 0.0f);
         F3 color = f3(0.0f, 0.0f, 0.0f);
-        for (uint32_t si = 0; si < fp.spp; ++si) {
-            uint32_t s = pix * fp.spp + si;
+        for (uint32_t si = 0; si < spp; ++si) {
+            uint32_t s = pix * spp + si;
             color = f3(io.term[s], io.term[cap + s], io.term[2 * cap + s]);
             sum = sum + color;
         }
-        if (fp.aa) color = unscale(sum, (float)fp.spp);   // mod.rs:248-249
+        if (fp.aa) color = unscale(sum, (float)spp);   // mod.rs:248-249
         PixelPos pp = pixel_of(fp, bp, pix);
         uint8_t* o = io.strip + (size_t)pp.strip_off * 3;
         o[0] = quantize(color.x);
@@ -929,7 +962,8 @@ void launch_setup(bool level0, uint32_t grid, hipStream_t st, const FrameParams&
 void launch_resolve(uint32_t grid_samples, uint32_t grid_pixels, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
                     const ResolveIO& io) {
     hipLaunchKernelGGL(k_resolve_samples, dim3(grid_samples), dim3(256), 0, st, fp, bp, io);
-    hipLaunchKernelGGL(k_resolve_pixels, dim3(grid_pixels), dim3(256), 0, st, fp, bp, io);
+    const bool per_sample = fp.spp >= 2u && fp.spp <= 64u && (fp.spp & (fp.spp - 1u)) == 0u;   // k_resolve_pixels' coalesced form
+    hipLaunchKernelGGL(k_resolve_pixels, dim3(per_sample ? grid_samples : grid_pixels), dim3(256), 0, st, fp, bp, io);
 }
 
 void launch_assemble(hipStream_t st, uint32_t width, uint32_t height, uint32_t bw, uint32_t bh, uint32_t nbx, uint32_t nby,
