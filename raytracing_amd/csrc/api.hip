@@ -66,6 +66,7 @@ struct trr_ctx {
     hipEvent_t fork = nullptr;
     DevBuf strip, frame, ids_obj, ids_tri;
     std::vector<hipEvent_t> events;
+    int bpc[2][2] = {{0, 0}, {0, 0}};    // resident 256-thread blocks per CU of k_trace<RAYGEN, COUNT> (occupancy query, once)
     uint64_t budget_total = 0;           // bytes the work sets of all lanes may take together (set at the first render)
     size_t events_used = 0;              // events handed to frames whose statistics are still pending
     // pinned read-back chunks (queue counters + kernel counters of one frame each), reused once collected
@@ -724,8 +725,17 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     const uint32_t cap = (uint32_t)(((uint64_t)blocks_per_batch * spb + 63) & ~63ull);
     const uint32_t D = std::max(1u, max_depth);
     // persistent trace grid: every CU gets as many 256-thread blocks as its registers / LDS admit
-    const int bpc = std::min(trace_blocks_per_cu(true, count), trace_blocks_per_cu(false, count));
-    const uint32_t trace_grid = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::max(1, std::min(bpc, 8));
+    // (each template instantiation has its own register count, hence its own number of resident blocks)
+    if (ctx->bpc[0][0] == 0)
+        for (int rg = 0; rg < 2; ++rg)
+            for (int cn = 0; cn < 2; ++cn) ctx->bpc[rg][cn] = std::max(1, std::min(trace_blocks_per_cu(rg != 0, cn != 0), 8));
+    // One grid for both: the smaller of the two counts.  Giving the secondary-ray launches their fifth block per CU was
+    // measured neutral to slightly slower (the free slots are what lets the other lanes' kernels in).
+    const uint32_t trace_grid = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::min(ctx->bpc[1][count ? 1 : 0], ctx->bpc[0][count ? 1 : 0]);
+    const uint32_t grid_raygen = trace_grid, grid_secondary = trace_grid;
+    if (std::getenv("TRR_DEBUG"))
+        std::fprintf(stderr, "trr: resident blocks per CU raygen %d secondary %d (count build: %d %d), lanes %u batches %llu\n",
+                     ctx->bpc[1][0], ctx->bpc[0][0], ctx->bpc[1][1], ctx->bpc[0][1], lanes, (unsigned long long)want_batches);
     const uint32_t aux_grid_max = (uint32_t)ctx->n_cu * 8;
     int rc;
     for (uint32_t k = 0; k < lanes; ++k) {
@@ -830,7 +840,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         tio.first_obj = ids_obj_dev;
         tio.first_tri = ids_tri_dev;
         ev_begin(0, s_);
-        launch_trace(true, count, trace_grid, s_, fp, bp, tio);
+        launch_trace(true, count, grid_raygen, s_, fp, bp, tio);
         ev_end(s_);
         // max_depth == 0: one setup pass turns every sample into skybox(ray.direction) (mod.rs:125-127), no secondary rays
         for (uint32_t lvl = 0; lvl < std::max(1u, max_depth); ++lvl) {
@@ -858,7 +868,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
             t2.first_obj = nullptr;
             t2.first_tri = nullptr;
             ev_begin(0, s_);
-            launch_trace(false, count, trace_grid, s_, fp, bp, t2);
+            launch_trace(false, count, grid_secondary, s_, fp, bp, t2);
             ev_end(s_);
         }
         ResolveIO rio{};
