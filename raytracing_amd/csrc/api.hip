@@ -729,10 +729,21 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     if (ctx->bpc[0][0] == 0)
         for (int rg = 0; rg < 2; ++rg)
             for (int cn = 0; cn < 2; ++cn) ctx->bpc[rg][cn] = std::max(1, std::min(trace_blocks_per_cu(rg != 0, cn != 0), 8));
-    // One grid for both: the smaller of the two counts.  Giving the secondary-ray launches their fifth block per CU was
-    // measured neutral to slightly slower (the free slots are what lets the other lanes' kernels in).
+    // Secondary-ray launches: the smaller of the two resident-block counts per CU (their fifth block was measured neutral
+    // to slightly slower).  Camera-ray launches: two blocks per CU -- most camera rays are short and coherent, and the
+    // slots they leave free let the other lanes' secondary launches in (grid sweep on MI355X: 4 -> 2 blocks per CU is
+    // -4 % frame time for the whole 4K frame, -9 % for an eighth of it).  TRR_GRID_BPC="raygen,secondary" overrides.
     const uint32_t trace_grid = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::min(ctx->bpc[1][count ? 1 : 0], ctx->bpc[0][count ? 1 : 0]);
-    const uint32_t grid_raygen = trace_grid, grid_secondary = trace_grid;
+    uint32_t grid_raygen = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::min(2, ctx->bpc[1][count ? 1 : 0]);
+    uint32_t grid_secondary = trace_grid;
+    const uint32_t spill_grid = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::max(ctx->bpc[1][count ? 1 : 0], ctx->bpc[0][count ? 1 : 0]);
+    if (const char* e = std::getenv("TRR_GRID_BPC")) {   // experiments: blocks per CU of the raygen / secondary launches
+        int a = 0, b = 0;
+        if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) {
+            grid_raygen = (uint32_t)ctx->n_cu * (uint32_t)std::min(a, ctx->bpc[1][count ? 1 : 0]);
+            grid_secondary = (uint32_t)ctx->n_cu * (uint32_t)std::min(b, ctx->bpc[0][count ? 1 : 0]);
+        }
+    }
     if (std::getenv("TRR_DEBUG"))
         std::fprintf(stderr, "trr: resident blocks per CU raygen %d secondary %d (count build: %d %d), lanes %u batches %llu\n",
                      ctx->bpc[1][0], ctx->bpc[0][0], ctx->bpc[1][1], ctx->bpc[0][1], lanes, (unsigned long long)want_batches);
@@ -746,7 +757,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
             (rc = ensure(ctx, w.shadow_q, (size_t)cap * sizeof(RayRec) * std::max(1u, L))) ||
             (rc = ensure(ctx, w.chain_q[0], (size_t)cap * sizeof(RayRec))) ||
             (rc = ensure(ctx, w.chain_q[1], (size_t)cap * sizeof(RayRec))) || (rc = ensure(ctx, w.counters, RB_STRIDE)) ||
-            (rc = ensure(ctx, w.spill, trace_spill_bytes(trace_grid))))
+            (rc = ensure(ctx, w.spill, trace_spill_bytes(spill_grid))))
             return rc;
     }
 
