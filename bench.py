@@ -43,8 +43,8 @@ def trace_bytes(st) -> float:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--spp", type=int, default=16)
@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="buffer sets / render streams alternated by consecutive frames (1 = each frame waits for the previous one)")
+    ap.add_argument("--no-launch-events", action="store_true",
+                    help="experiment: time the frames without per-launch HIP events (the roofline object is then null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "16")))
     args = ap.parse_args()
@@ -105,7 +107,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        sr.render(stats=stats[k], defer_stats=True)   # events are recorded now, read after the timed region
+        sr.render(stats=None if args.no_launch_events else stats[k], defer_stats=True)   # events recorded now, read after the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
     rt.ctx.collect_stats()
@@ -115,6 +117,9 @@ def main():
         elapsed = float(t.item())
 
     # rays of the whole frame = sum over ranks of their shard's rays (deterministic per frame)
+    if args.no_launch_events:   # ray counts from one untimed frame
+        sr.render(stats=stats[-1])
+        torch.cuda.synchronize()
     my_rays = stats[-1].rays() if stats else 0
     if distributed:
         t = torch.tensor([my_rays], dtype=torch.int64, device="cuda")
@@ -128,7 +133,7 @@ def main():
     cst = N.Stats()
     sr.render(stats=cst, counters=True)
     torch.cuda.synchronize()
-    if rank == 0 and args.steps > 0:
+    if rank == 0 and args.steps > 0 and not args.no_launch_events:
         launches = sum(s.trace_launches for s in stats)
         ms_trace = sum(s.ms_trace for s in stats)
         avg_ms = ms_trace / max(1, launches)
