@@ -175,7 +175,7 @@ constexpr uint8_t NLEV_PENDING = 0xFF;   // nlev value of a camera sample whose 
 constexpr int STACK_LDS = TRR_STACK_LDS;       // per-lane (ref, tmin) entries kept in LDS
 constexpr int STACK_SPILL = 64 - STACK_LDS;     // further entries in a per-thread HBM spill area (rarely touched)
 #ifndef TRR_REFILL_MIN
-#define TRR_REFILL_MIN 20
+#define TRR_REFILL_MIN 36
 #endif
 constexpr int REFILL_MIN = TRR_REFILL_MIN;      // re-fill when at least this many of the 64 lanes are idle
 #ifndef TRR_PRUNE_REL
@@ -193,7 +193,7 @@ constexpr int NODE_BIAS = TRR_NODE_BIAS;
 #define TRR_CHUNK_DIV 8
 #endif
 #ifndef TRR_CHUNK_MAX
-#define TRR_CHUNK_MAX 256
+#define TRR_CHUNK_MAX 512
 #endif
 constexpr uint32_t CHUNK_MAX = TRR_CHUNK_MAX;
 constexpr uint32_t CHUNK_DIV = TRR_CHUNK_DIV;   // a claim takes 1/CHUNK_DIV of the remaining work per wavefront   // a node step runs when 8ths-weighted inner lanes >= leaf lanes
