@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Measures the five BASELINE.json configurations on ONE GPU (stand-in scenes) next to the CPU restatement.
+
+GPU: ms/frame of a sequence of frames (device-resident, no host synchronisation between frames) and Mrays/s with the
+ray accounting of SURVEY.md 8(d).  CPU: oracle/ in reference-literal mode on every k-th block (k chosen so that the
+sample holds about 30 M rays), all host threads the box grants, credited the GPU's ray count for the same blocks; the
+sampled blocks are compared byte for byte.  Writes one JSON line per configuration.
+Usage (GPU box): python scripts/measure_configs.py [--configs 1,2,3,4,5] > gpurun_out/configs.jsonl"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="1,2,3,4,5")
+    ap.add_argument("--frames", type=int, default=6)
+    ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "16")))
+    ap.add_argument("--cpu-rays", type=float, default=30e6, help="target size of the CPU sample in rays")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from raytracing_amd import _native as N
+    from raytracing_amd import standin
+    from raytracing_amd.multigpu import strip_from_frame
+    from raytracing_amd.raytracer import Raytracer
+
+    cfgs = {
+        1: ("res/test stand-in (floor 0.3 M + car 1.0 M triangles) 800x600, 1 spp, max_depth 2",
+            lambda: standin.standin_test(800, 600), 2),
+        2: ("car_objs stand-in (1.0 M triangles) 1920x1080, 1 spp, max_depth 5",
+            lambda: standin.standin_car(1920, 1080), 5),
+        3: ("car_objs stand-in (1.0 M triangles) 3840x2160, 16 spp, max_depth 5",
+            lambda: standin.standin_car(3840, 2160, anti_aliasing=True, samples=16), 5),
+        4: ("10 M-triangle terrain stand-in 3840x2160, 1 spp, max_depth 5",
+            lambda: standin.standin_terrain(3840, 2160), 5),
+        5: ("mirror spheres + image sky stand-in 3840x2160, 1 spp, max_depth 9",
+            lambda: standin.standin_mirrors(3840, 2160), 9),
+    }
+    for c in [int(x) for x in args.configs.split(",")]:
+        name, make, md = cfgs[c]
+        t0 = time.perf_counter()
+        sc = make()
+        gen_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        rt = Raytracer(sc, max_depth=md)
+        upload_s = time.perf_counter() - t0
+        w, h = sc.camera.resolution
+        sb = rt.strip_bytes(1)
+        strip = torch.zeros(sb, dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        st = N.Stats()
+        rt.render_shard_device(0, 1, strip.data_ptr(), sb, stream=stream.cuda_stream, stats=st)
+        torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter()
+            for _k in range(args.frames):
+                rt.render_shard_device(0, 1, strip.data_ptr(), sb, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / args.frames)
+        cst = N.Stats()
+        rt.render_shard_device(0, 1, strip.data_ptr(), sb, stream=stream.cuda_stream, stats=cst, counters=True)
+        torch.cuda.synchronize()
+        rec = {"config": c, "workload": name, "triangles": sc.triangle_count(), "resolution": [w, h], "max_depth": md,
+               "gpu_ms_per_frame": round(best * 1e3, 3), "rays_per_frame": int(st.rays()),
+               "gpu_mrays_per_s": round(st.rays() / best / 1e6, 1), "scene_upload_s": round(upload_s, 2),
+               "nodes_per_ray": round(cst.node_visits / max(1, cst.rays()), 2),
+               "tris_per_ray": round(cst.tri_tests / max(1, cst.rays()), 2),
+               "rays": {"primary": int(st.rays_primary), "shadow": int(st.rays_shadow), "reflection": int(st.rays_reflection)}}
+        if not args.no_cpu:
+            from oracle import oracle
+            step = int(max(1, min(100, round(st.rays() / args.cpu_rays))))
+            gst = N.Stats()
+            sbs = rt.strip_bytes(step)
+            tmp = torch.zeros(sbs, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            rt.render_shard_device(0, step, tmp.data_ptr(), sbs, stats=gst)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            osc = oracle.OracleScene(sc)
+            res = osc.render(max_depth=md, accel=oracle.ACCEL_BVH, shade=oracle.SHADE_LITERAL, threads=args.cpu_threads,
+                             block_first=0, block_step=step, want_ids=False)
+            cn = res["counters"]
+            ref = strip_from_frame(res["rgb"], 0, step)
+            nb = len(range(0, 400, step))
+            npx = nb * (w // 20) * (h // 20)
+            d = np.abs(tmp.cpu().numpy()[:npx * 3].astype(np.int16) - ref[:npx * 3].astype(np.int16)).reshape(-1, 3).max(axis=1)
+            rec.update({"cpu_sample": f"blocks 0::{step} ({nb} of 400)", "cpu_threads": args.cpu_threads,
+                        "cpu_seconds": round(cn.seconds, 3), "cpu_mrays_per_s": round(gst.rays() / cn.seconds / 1e6, 3),
+                        "cpu_ms_per_frame_extrapolated": round(cn.seconds * st.rays() / max(1, gst.rays()) * 1e3, 1),
+                        "cpu_setup_s": round(time.perf_counter() - t0 - cn.seconds, 1),
+                        "parity_exact": round(float((d == 0).mean()), 6), "parity_within_1lsb": round(float((d <= 1).mean()), 6)})
+            rec["speedup"] = round(rec["gpu_mrays_per_s"] / rec["cpu_mrays_per_s"], 1)
+            osc.close()
+        print(json.dumps(rec), flush=True)
+        rt.close()
+        del strip
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
