@@ -1,0 +1,230 @@
+// render_cpp -- the C++ host layer (include/trayracer.hpp) end to end, no Python and no PyTorch in the process:
+// builds a small scene from exactly representable numbers, renders it through trayracer::Render (render thread,
+// progress, cancel -- the handle of raytracer/render.rs:15-25), writes the frame as PPM and the scene as a flat binary
+// dump.  tests/test_gpu_cpp_host.py reads the dump back, renders the same scene through the Python binding and the CPU
+// oracle and compares the three frames.
+//
+//   usage: render_cpp <out.ppm> <scene.bin> [width height]
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "trayracer.hpp"
+
+using namespace trayracer;
+
+static Triangle tri(Vec3 a, Vec3 b, Vec3 c, Vec3 n, std::array<float, 2> ua, std::array<float, 2> ub, std::array<float, 2> uc,
+                    std::optional<size_t> mat) {
+    Triangle t;
+    t.a = a; t.b = b; t.c = c;
+    t.a_normal = t.b_normal = t.c_normal = n;
+    t.a_uv = ua; t.b_uv = ub; t.c_uv = uc;
+    t.material_index = mat;
+    return t;
+}
+
+// axis-aligned quad p0 + s*u + t*v, two triangles
+static void quad(std::vector<Triangle>& out, Vec3 p, Vec3 u, Vec3 v, Vec3 n, std::optional<size_t> mat) {
+    Vec3 p1{p[0] + u[0], p[1] + u[1], p[2] + u[2]}, p3{p[0] + v[0], p[1] + v[1], p[2] + v[2]};
+    Vec3 p2{p1[0] + v[0], p1[1] + v[1], p1[2] + v[2]};
+    out.push_back(tri(p, p1, p2, n, {0, 0}, {1, 0}, {1, 1}, mat));
+    out.push_back(tri(p, p2, p3, n, {0, 0}, {1, 1}, {0, 1}, mat));
+}
+
+static void box(std::vector<Triangle>& out, Vec3 lo, Vec3 hi, std::optional<size_t> mat) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    quad(out, {lo[0], hi[1], lo[2]}, {0, 0, dz}, {dx, 0, 0}, {0, 1, 0}, mat);    // top
+    quad(out, {lo[0], lo[1], lo[2]}, {dx, 0, 0}, {0, 0, dz}, {0, -1, 0}, mat);   // bottom
+    quad(out, {lo[0], lo[1], hi[2]}, {dx, 0, 0}, {0, dy, 0}, {0, 0, 1}, mat);    // front
+    quad(out, {lo[0], lo[1], lo[2]}, {0, dy, 0}, {dx, 0, 0}, {0, 0, -1}, mat);   // back
+    quad(out, {hi[0], lo[1], lo[2]}, {0, dy, 0}, {0, 0, dz}, {1, 0, 0}, mat);    // right
+    quad(out, {lo[0], lo[1], lo[2]}, {0, 0, dz}, {0, dy, 0}, {-1, 0, 0}, mat);   // left
+}
+
+static Scene make_scene(uint32_t w, uint32_t h) {
+    Scene sc;
+    // floor: 16 x 16 mirror tiles (illum 3), translated like res/test/config.yaml places its models
+    Object floor;
+    floor.name = "Floor";
+    Material mirror;
+    mirror.name = "floor";
+    mirror.diffuse_color = Color{0.0625f, 0.0625f, 0.0625f};
+    mirror.specular_color = Color{0.5f, 0.5f, 0.5f};
+    mirror.specular_exponent = 64.0f;
+    mirror.illumination_model = *IlluminationModel::from_i32(3);
+    mirror.dissolve = 0.0f;
+    floor.materials.push_back(mirror);
+    for (int j = 0; j < 16; ++j)
+        for (int i = 0; i < 16; ++i)
+            quad(floor.triangles, {-4.0f + 0.5f * i, 0.0f, -4.0f + 0.5f * j}, {0, 0, 0.5f}, {0.5f, 0, 0}, {0, 1, 0}, 0);
+    floor.translation = {0.5f, 0.0f, -0.25f};
+    sc.objects.push_back(floor);
+
+    // props: a red specular box, a textured box, a glass pane (illum 6, dissolve 0.5), a chrome box without Ks/Ns/d and
+    // one face without any material; rotated a quarter turn about y and scaled non-uniformly
+    Object props;
+    props.name = "Props";
+    auto tex = std::make_shared<Image>();
+    tex->width = 4; tex->height = 4;
+    for (int y = 0; y < 4; ++y)
+        for (int x = 0; x < 4; ++x) {
+            bool on = ((x ^ y) & 1) != 0;
+            tex->rgb.insert(tex->rgb.end(), {(uint8_t)(on ? 200 : 40), (uint8_t)(on ? 60 : 40), (uint8_t)(on ? 30 : 160)});
+        }
+    Material red; red.name = "red"; red.diffuse_color = Color{0.75f, 0.125f, 0.125f}; red.specular_color = Color{0.5f, 0.5f, 0.5f};
+    red.specular_exponent = 32.0f; red.illumination_model = *IlluminationModel::from_i32(2); red.dissolve = 0.0f;
+    Material checker; checker.name = "checker"; checker.diffuse_color = Color{0.25f, 0.25f, 0.25f}; checker.diffuse_texture = tex;
+    checker.illumination_model = *IlluminationModel::from_i32(2); checker.specular_exponent = 8.0f;
+    Material glass; glass.name = "glass"; glass.diffuse_color = Color{0.5f, 0.75f, 1.0f}; glass.dissolve = 0.5f;
+    glass.illumination_model = *IlluminationModel::from_i32(6);
+    Material chrome; chrome.name = "chrome"; chrome.diffuse_color = Color{0.125f, 0.125f, 0.1875f};
+    chrome.illumination_model = *IlluminationModel::from_i32(4);
+    props.materials = {red, checker, glass, chrome};
+    box(props.triangles, {-0.5f, 0.0f, -0.5f}, {0.5f, 1.0f, 0.5f}, 0);
+    box(props.triangles, {1.0f, 0.0f, -1.5f}, {1.75f, 0.75f, -0.75f}, 1);
+    quad(props.triangles, {-1.5f, 0.0f, 1.25f}, {1.5f, 0, 0}, {0, 1.25f, 0}, {0, 0, 1}, 2);
+    box(props.triangles, {-2.0f, 0.0f, -1.0f}, {-1.25f, 1.5f, -0.25f}, 3);
+    quad(props.triangles, {0.75f, 0.0f, 0.75f}, {0.75f, 0, 0}, {0, 0.75f, 0}, {0, 0, 1}, std::nullopt);
+    props.translation = {0.25f, 0.0f, 0.5f};
+    props.rotation = {0.0f, 0.70710677f, 0.0f, 0.70710677f};
+    props.scale = {1.0f, 1.25f, 0.75f};
+    sc.objects.push_back(props);
+
+    sc.lights.push_back(Light::from_ke({-2.0f, 3.5f, -0.75f}, {1, 1, 1}, 40.0f));
+    sc.lights.push_back(Light::from_ke({5.5f, 0.25f, -4.5f}, {0.75f, 0.25f, 0.75f}, 22.0f));
+    sc.lights.push_back(Light::from_ke({2.0f, 4.0f, 1.5f}, {1, 1, 1}, 23.0f));
+    sc.camera.position = {3.5f, 2.25f, 5.0f};
+    sc.camera.look_at = {0.0f, 0.5f, 0.0f};
+    sc.camera.up = {0, 1, 0};
+    sc.camera.fov = 1.0f;
+    sc.camera.resolution = {w, h};
+    // a small image sky: 8 x 4 gradient
+    auto sky = std::make_shared<Image>();
+    sky->width = 8; sky->height = 4;
+    for (int y = 0; y < 4; ++y)
+        for (int x = 0; x < 8; ++x) sky->rgb.insert(sky->rgb.end(), {(uint8_t)(30 + 20 * x), (uint8_t)(60 + 40 * y), (uint8_t)(220 - 15 * x)});
+    sc.settings.skybox = std::shared_ptr<const Image>(sky);
+    return sc;
+}
+
+// flat little-endian dump read by tests/test_gpu_cpp_host.py
+template <typename T> static void put(std::ofstream& f, const T& v) { f.write(reinterpret_cast<const char*>(&v), sizeof v); }
+static void put_image(std::ofstream& f, const Image* im) {
+    put<uint32_t>(f, im ? im->width : 0);
+    put<uint32_t>(f, im ? im->height : 0);
+    if (im) f.write(reinterpret_cast<const char*>(im->rgb.data()), (std::streamsize)im->rgb.size());
+}
+static void dump_scene(const Scene& sc, const char* path) {
+    std::ofstream f(path, std::ios::binary);
+    f.write("TRRSCN01", 8);
+    put<uint32_t>(f, (uint32_t)sc.objects.size());
+    for (const Object& o : sc.objects) {
+        put<uint32_t>(f, (uint32_t)o.triangles.size());
+        for (const Triangle& t : o.triangles) {
+            for (const Vec3* v : {&t.a, &t.b, &t.c, &t.a_normal, &t.b_normal, &t.c_normal}) f.write(reinterpret_cast<const char*>(v->data()), 12);
+            for (const auto* v : {&t.a_uv, &t.b_uv, &t.c_uv}) f.write(reinterpret_cast<const char*>(v->data()), 8);
+            put<int32_t>(f, t.material_index ? (int32_t)*t.material_index : -1);
+        }
+        put<uint32_t>(f, (uint32_t)o.materials.size());
+        for (const Material& m : o.materials) {
+            uint32_t flags = (m.diffuse_color ? 1u : 0u) | (m.specular_color ? 2u : 0u) | (m.specular_exponent ? 4u : 0u) | (m.dissolve ? 8u : 0u);
+            put<uint32_t>(f, flags);
+            Color kd = m.diffuse_color.value_or(Color{0, 0, 0}), ks = m.specular_color.value_or(Color{0, 0, 0});
+            f.write(reinterpret_cast<const char*>(kd.data()), 12);
+            f.write(reinterpret_cast<const char*>(ks.data()), 12);
+            put<float>(f, m.specular_exponent.value_or(0.0f));
+            put<float>(f, m.dissolve.value_or(0.0f));
+            put<int32_t>(f, m.illumination_model.value);
+            put_image(f, m.diffuse_texture.get());
+        }
+        f.write(reinterpret_cast<const char*>(o.translation.data()), 12);
+        f.write(reinterpret_cast<const char*>(o.rotation.data()), 16);
+        f.write(reinterpret_cast<const char*>(o.scale.data()), 12);
+    }
+    put<uint32_t>(f, (uint32_t)sc.lights.size());
+    for (const Light& l : sc.lights) {
+        f.write(reinterpret_cast<const char*>(l.position.data()), 12);
+        f.write(reinterpret_cast<const char*>(l.color.data()), 12);
+        put<float>(f, l.intensity);
+    }
+    const Settings& s = sc.settings;
+    put<uint32_t>(f, s.samples);
+    put<uint32_t>(f, s.anti_aliasing ? 1u : 0u);
+    put<uint64_t>(f, s.seed);
+    f.write(reinterpret_cast<const char*>(s.ambient_color.data()), 12);
+    put<float>(f, s.ambient_intensity);
+    if (auto img = std::get_if<std::shared_ptr<const Image>>(&s.skybox)) {
+        put<uint32_t>(f, 1);
+        put_image(f, img->get());
+    } else {
+        put<uint32_t>(f, 0);
+        f.write(reinterpret_cast<const char*>(std::get<Color>(s.skybox).data()), 12);
+    }
+    const Camera& c = sc.camera;
+    f.write(reinterpret_cast<const char*>(c.position.data()), 12);
+    f.write(reinterpret_cast<const char*>(c.look_at.data()), 12);
+    f.write(reinterpret_cast<const char*>(c.up.data()), 12);
+    put<float>(f, c.fov);
+    put<uint32_t>(f, c.resolution.first);
+    put<uint32_t>(f, c.resolution.second);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: %s <out.ppm> <scene.bin> [width height]\n", argv[0]);
+        return 2;
+    }
+    uint32_t w = argc > 4 ? (uint32_t)std::atoi(argv[3]) : 320, h = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 240;
+    try {
+        Scene sc = make_scene(w, h);
+        dump_scene(sc, argv[2]);
+        auto ctx = std::make_shared<Context>(0);
+        Render r(ctx);
+
+        // 1. a cancelled render: the flag is already set when the thread starts (render.rs:113), so no block is rendered
+        r.cancel = 1;
+        r.render(sc);
+        r.thread->join();   // (Render::join() would also clear the flag; the check below wants to see it first)
+        bool cancelled_black = true;
+        for (uint8_t v : r.image.rgb) cancelled_black = cancelled_black && v == 0;
+        std::printf("cancelled render: finished=%d black=%d\n", (int)r.finished(), (int)cancelled_black);
+        r.join();
+
+        // 2. the real render, polled like the UI does (ui/mod.rs:93-100)
+        r.render(sc);
+        uint16_t last = 0;
+        int polls = 0;
+        while (!r.finished()) {
+            uint16_t p = r.progress.load();
+            if (p < last) { std::fprintf(stderr, "progress went backwards\n"); return 1; }
+            last = p;
+            ++polls;
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        r.join();
+        if (!r.error.empty()) { std::fprintf(stderr, "render failed: %s\n", r.error.c_str()); return 1; }
+        std::printf("render: %ux%u in %u ms, progress=%u, polls=%d\n", r.image.width, r.image.height, r.time.load(), (unsigned)r.progress.load(), polls);
+
+        // 3. the error path: a resolution below 20 px is the reference's division by zero (render.rs:109)
+        Scene tiny = sc;
+        tiny.camera.resolution = {16, 16};
+        int code = 0;
+        try {
+            Raytracer rt(ctx, tiny);
+            std::vector<uint8_t> px(16 * 16 * 3);
+            rt.render_frame(px.data());
+        } catch (const Error& e) { code = e.code; }
+        std::printf("16x16 render: error code %d\n", code);
+
+        std::ofstream f(argv[1], std::ios::binary);
+        f << "P6\n" << r.image.width << " " << r.image.height << "\n255\n";
+        f.write(reinterpret_cast<const char*>(r.image.rgb.data()), (std::streamsize)r.image.rgb.size());
+        unsigned long long sum = 0;
+        for (uint8_t v : r.image.rgb) sum += v;
+        std::printf("checksum %llu\n", sum);
+        return (cancelled_black && code == TRR_ERR_RESOLUTION) ? 0 : 1;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+}

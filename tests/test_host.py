@@ -145,3 +145,14 @@ def test_two_rank_gloo_gather_assembles_the_frame():
     frame[nby * bh:, :] = 0
     frame[:, nbx * bw:] = 0
     assert np.array_equal(out, frame)
+
+
+def test_cpp_host_header_compiles_standalone(tmp_path):
+    """include/trayracer.hpp is self-contained C++17 over the C header (syntax check only, no GPU and no linking)."""
+    import subprocess
+    src = os.path.join(str(tmp_path), "t.cpp")
+    with open(src, "w") as f:
+        f.write('#include "trayracer.hpp"\nint main() { trayracer::Scene s; trayracer::Settings st; return (int)s.objects.size() + (int)st.samples - 1; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    p = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, src], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
