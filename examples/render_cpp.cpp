@@ -9,6 +9,7 @@
 #include <cstring>
 #include <fstream>
 
+#include "scene_dump.hpp"
 #include "trayracer.hpp"
 
 using namespace trayracer;
@@ -105,68 +106,6 @@ static Scene make_scene(uint32_t w, uint32_t h) {
         for (int x = 0; x < 8; ++x) sky->rgb.insert(sky->rgb.end(), {(uint8_t)(30 + 20 * x), (uint8_t)(60 + 40 * y), (uint8_t)(220 - 15 * x)});
     sc.settings.skybox = std::shared_ptr<const Image>(sky);
     return sc;
-}
-
-// flat little-endian dump read by tests/test_gpu_cpp_host.py
-template <typename T> static void put(std::ofstream& f, const T& v) { f.write(reinterpret_cast<const char*>(&v), sizeof v); }
-static void put_image(std::ofstream& f, const Image* im) {
-    put<uint32_t>(f, im ? im->width : 0);
-    put<uint32_t>(f, im ? im->height : 0);
-    if (im) f.write(reinterpret_cast<const char*>(im->rgb.data()), (std::streamsize)im->rgb.size());
-}
-static void dump_scene(const Scene& sc, const char* path) {
-    std::ofstream f(path, std::ios::binary);
-    f.write("TRRSCN01", 8);
-    put<uint32_t>(f, (uint32_t)sc.objects.size());
-    for (const Object& o : sc.objects) {
-        put<uint32_t>(f, (uint32_t)o.triangles.size());
-        for (const Triangle& t : o.triangles) {
-            for (const Vec3* v : {&t.a, &t.b, &t.c, &t.a_normal, &t.b_normal, &t.c_normal}) f.write(reinterpret_cast<const char*>(v->data()), 12);
-            for (const auto* v : {&t.a_uv, &t.b_uv, &t.c_uv}) f.write(reinterpret_cast<const char*>(v->data()), 8);
-            put<int32_t>(f, t.material_index ? (int32_t)*t.material_index : -1);
-        }
-        put<uint32_t>(f, (uint32_t)o.materials.size());
-        for (const Material& m : o.materials) {
-            uint32_t flags = (m.diffuse_color ? 1u : 0u) | (m.specular_color ? 2u : 0u) | (m.specular_exponent ? 4u : 0u) | (m.dissolve ? 8u : 0u);
-            put<uint32_t>(f, flags);
-            Color kd = m.diffuse_color.value_or(Color{0, 0, 0}), ks = m.specular_color.value_or(Color{0, 0, 0});
-            f.write(reinterpret_cast<const char*>(kd.data()), 12);
-            f.write(reinterpret_cast<const char*>(ks.data()), 12);
-            put<float>(f, m.specular_exponent.value_or(0.0f));
-            put<float>(f, m.dissolve.value_or(0.0f));
-            put<int32_t>(f, m.illumination_model.value);
-            put_image(f, m.diffuse_texture.get());
-        }
-        f.write(reinterpret_cast<const char*>(o.translation.data()), 12);
-        f.write(reinterpret_cast<const char*>(o.rotation.data()), 16);
-        f.write(reinterpret_cast<const char*>(o.scale.data()), 12);
-    }
-    put<uint32_t>(f, (uint32_t)sc.lights.size());
-    for (const Light& l : sc.lights) {
-        f.write(reinterpret_cast<const char*>(l.position.data()), 12);
-        f.write(reinterpret_cast<const char*>(l.color.data()), 12);
-        put<float>(f, l.intensity);
-    }
-    const Settings& s = sc.settings;
-    put<uint32_t>(f, s.samples);
-    put<uint32_t>(f, s.anti_aliasing ? 1u : 0u);
-    put<uint64_t>(f, s.seed);
-    f.write(reinterpret_cast<const char*>(s.ambient_color.data()), 12);
-    put<float>(f, s.ambient_intensity);
-    if (auto img = std::get_if<std::shared_ptr<const Image>>(&s.skybox)) {
-        put<uint32_t>(f, 1);
-        put_image(f, img->get());
-    } else {
-        put<uint32_t>(f, 0);
-        f.write(reinterpret_cast<const char*>(std::get<Color>(s.skybox).data()), 12);
-    }
-    const Camera& c = sc.camera;
-    f.write(reinterpret_cast<const char*>(c.position.data()), 12);
-    f.write(reinterpret_cast<const char*>(c.look_at.data()), 12);
-    f.write(reinterpret_cast<const char*>(c.up.data()), 12);
-    put<float>(f, c.fov);
-    put<uint32_t>(f, c.resolution.first);
-    put<uint32_t>(f, c.resolution.second);
 }
 
 int main(int argc, char** argv) {

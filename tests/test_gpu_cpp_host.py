@@ -3,71 +3,18 @@ Render interface) end to end.  examples/render_cpp is a plain g++ program: no Py
 renders its scene through trayracer::Render, writes the frame and a dump of the scene; the same scene is then rendered
 through the Python binding and by the CPU oracle, and the three frames are compared."""
 import os
-import struct
 import subprocess
 
 import numpy as np
 import pytest
 
 from raytracing_amd.raytracer import Raytracer
-from raytracing_amd.scene import Camera, IlluminationModel, Light, Material, Object, Scene, Settings, Skybox
-from tests._util import assert_parity
+from raytracing_amd.scene import Light, Settings
+from tests._util import assert_parity, read_scene_dump
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "examples", "render_cpp")
-
-
-class _Reader:
-    def __init__(self, data):
-        self.d, self.o = data, 0
-
-    def take(self, fmt):
-        v = struct.unpack_from("<" + fmt, self.d, self.o)
-        self.o += struct.calcsize("<" + fmt)
-        return v if len(v) > 1 else v[0]
-
-    def array(self, dtype, n):
-        a = np.frombuffer(self.d, dtype, n, self.o).copy()
-        self.o += a.nbytes
-        return a
-
-    def image(self):
-        w, h = self.take("II")
-        return self.array(np.uint8, w * h * 3).reshape(h, w, 3) if w * h else None
-
-
-def read_scene_dump(path) -> Scene:
-    r = _Reader(open(path, "rb").read())
-    assert r.d[:8] == b"TRRSCN01"
-    r.o = 8
-    objects = []
-    for _ in range(r.take("I")):
-        nt = r.take("I")
-        rec = r.array(np.dtype([("f", "<f4", 24), ("m", "<i4")]), nt)
-        mats = []
-        for _k in range(r.take("I")):
-            flags = r.take("I")
-            kd, ks = r.array(np.float32, 3), r.array(np.float32, 3)
-            ns, dis, illum = r.take("f"), r.take("f"), r.take("i")
-            tex = r.image()
-            mats.append(Material(diffuse_color=kd if flags & 1 else None, specular_color=ks if flags & 2 else None,
-                                 specular_exponent=ns if flags & 4 else None, dissolve=dis if flags & 8 else None,
-                                 illumination_model=IlluminationModel(illum), diffuse_texture=tex))
-        t, q, s = r.array(np.float32, 3), r.array(np.float32, 4), r.array(np.float32, 3)
-        objects.append(Object(triangles=rec["f"], material_index=rec["m"], materials=mats, translation=t, rotation=q, scale=s))
-    lights = []
-    for _ in range(r.take("I")):
-        p, c = r.array(np.float32, 3), r.array(np.float32, 3)
-        lights.append(Light(p, c, r.take("f")))
-    samples, aa, seed = r.take("I"), r.take("I"), r.take("Q")
-    amb, amb_i = r.array(np.float32, 3), r.take("f")
-    sky = Skybox(image=r.image()) if r.take("I") else Skybox(color=r.array(np.float32, 3))
-    st = Settings(samples=samples, anti_aliasing=bool(aa), seed=seed, ambient_color=amb, ambient_intensity=amb_i, skybox=sky)
-    pos, look, up = r.array(np.float32, 3), r.array(np.float32, 3), r.array(np.float32, 3)
-    fov, w, h = r.take("f"), r.take("I"), r.take("I")
-    assert r.o == len(r.d)
-    return Scene(objects=objects, lights=lights, camera=Camera(pos, look, up, fov, (w, h)), settings=st)
 
 
 def test_cpp_host_layer_renders_the_same_frame(tmp_path, oracle_mod):

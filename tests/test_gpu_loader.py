@@ -51,3 +51,22 @@ def test_cli_writes_the_rendered_frame(scene_dir, tmp_path, capsys):
         rt.close()
     assert np.array_equal(load_image_rgb8(png), want)
     assert cli.main([os.path.join(str(tmp_path), "absent.yaml")]) == 2
+
+
+def test_cpp_cli_renders_the_same_frame(scene_dir, tmp_path):
+    """examples/trr_cli (C++ loader + C++ host layer, no Python in its process) on the same files."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "trr_cli")
+    assert os.path.exists(exe)
+    png = os.path.join(str(tmp_path), "cpp.png")
+    p = subprocess.run([exe, scene_dir, "-o", png, "--max-depth", "4", "--stats"], capture_output=True, text=True, timeout=100)
+    assert p.returncode == 0, p.stdout + p.stderr
+    info = json.loads(p.stdout.strip().splitlines()[-1])
+    assert info["resolution"] == [160, 120] and info["rays"] > 160 * 120
+    sc = load_scene(scene_dir)
+    rt = Raytracer(sc, max_depth=4)
+    try:
+        want = rt.render_frame()["rgb"]
+    finally:
+        rt.close()
+    assert np.array_equal(load_image_rgb8(png), want)
