@@ -153,6 +153,9 @@ int trr_scene_set_camera(trr_scene* scene, const trr_camera* camera);
 #define TRR_FLAG_DEFER_STATS 2u /* trr_render_shard_device with stats_out: do not wait for the frame; *stats_out is
                                  * filled by the next trr_collect_stats (stats_out must stay valid until then).  Lets
                                  * a caller keep several frames in flight and still get per-launch timings. */
+#define TRR_FLAG_PIPELINED 4u   /* trr_render_shard_device: the caller keeps two frames in flight, consecutive frames on
+                                 * different streams and strips.  A shard that fits one batch is then rendered as one
+                                 * batch, frames alternating between two work sets, instead of two batches per frame. */
 
 /* Replaces the block loop of RenderingThread::run (render.rs:103-152) for the whole frame: writes
  * row-major RGB8 (width*height*3, remainder strip left 0,0,0 as render.rs:100-102) into host memory.

@@ -21,6 +21,7 @@ TRR_ERR_NOMEM = -5
 TRR_MAT_HAS_KD, TRR_MAT_HAS_KS, TRR_MAT_HAS_NS, TRR_MAT_HAS_DISSOLVE = 1, 2, 4, 8
 TRR_FLAG_COUNTERS = 1
 TRR_FLAG_DEFER_STATS = 2
+TRR_FLAG_PIPELINED = 4
 
 
 class MaterialDesc(C.Structure):

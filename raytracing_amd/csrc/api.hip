@@ -67,6 +67,7 @@ struct trr_ctx {
     DevBuf strip, frame, ids_obj, ids_tri;
     std::vector<hipEvent_t> events;
     int bpc[2][2] = {{0, 0}, {0, 0}};    // resident 256-thread blocks per CU of k_trace<RAYGEN, COUNT> (occupancy query, once)
+    uint32_t rotate = 0;                 // round-robin start lane of single-batch frames
     uint64_t budget_total = 0;           // bytes the work sets of all lanes may take together (set at the first render)
     size_t events_used = 0;              // events handed to frames whose statistics are still pending
     // pinned read-back chunks (queue counters + kernel counters of one frame each), reused once collected
@@ -707,6 +708,12 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         want_batches = (uint64_t)std::max(1, std::atoi(e));
         lanes_want = e_lanes ? lanes_want : (uint32_t)std::min<uint64_t>(3, want_batches);
     }
+    // A caller that keeps two frames in flight (TRR_FLAG_PIPELINED) and whose shard fits one batch: one batch per frame,
+    // frames alternating between two work sets (measured: -9 % per frame for a quarter / an eighth of the 4K frame
+    // against two half-size batches per frame; a lone frame would be slower this way, hence the flag).
+    const bool pipelined_single = !interactive && !e_lanes && !e_bpl && !std::getenv("TRR_BATCHES") &&
+                                  (flags & TRR_FLAG_PIPELINED) != 0 && total_samples <= (1ull << 25);
+    if (pipelined_single) { want_batches = 1; lanes_want = 1; }
     if (interactive) want_batches = 1;   // polled per batch: keep batches in order, as large as memory allows
     want_batches = std::min<uint64_t>(want_batches, n_owned);
     const uint32_t lanes = interactive ? 1u : (uint32_t)std::min<uint64_t>(lanes_want, want_batches);
@@ -749,7 +756,16 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
                      ctx->bpc[1][0], ctx->bpc[0][0], ctx->bpc[1][1], ctx->bpc[0][1], lanes, (unsigned long long)want_batches);
     const uint32_t aux_grid_max = (uint32_t)ctx->n_cu * 8;
     int rc;
-    for (uint32_t k = 0; k < lanes; ++k) {
+    // `pool` work sets may be used by this call: its `lanes` consecutive ones starting at lane_base.  A single-batch frame
+    // of a pipelined caller (TRR_FLAG_PIPELINED) takes the two sets in turn, so that consecutive frames, queued on
+    // different streams, overlap each other instead of two half-size batches of the same frame.
+    uint32_t pool = lanes, lane_base = 0;
+    if (pipelined_single) {
+        pool = 2;
+        if (const char* e = std::getenv("TRR_POOL")) pool = (uint32_t)std::min(trr_ctx::MAX_LANES, std::max(2, std::atoi(e)));
+        lane_base = ctx->rotate++ % pool;
+    }
+    for (uint32_t k = 0; k < pool; ++k) {
         trr_ctx::WorkSet& w = ctx->ws[k];
         if ((rc = ensure(ctx, w.hits, (size_t)cap * sizeof(HitRec))) || (rc = ensure(ctx, w.level, (size_t)cap * 4 * LEVEL_PLANES * D)) ||
             (rc = ensure(ctx, w.term, (size_t)cap * 12)) || (rc = ensure(ctx, w.nlev, (size_t)cap)) ||
@@ -816,10 +832,14 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
 
     // fork: with one lane everything stays on the caller's stream; with several, every lane stream waits for what
     // the caller's stream has queued so far (the strip clear) and the caller's stream later waits for every lane
-    const bool forked = lanes > 1;
+    const bool forked = pool > 1;
     if (forked) {
         HIPCHK(ctx, hipEventRecord(ctx->fork, st));
-        for (uint32_t k = 0; k < lanes; ++k) HIPCHK(ctx, hipStreamWaitEvent(ctx->ws[k].stream, ctx->fork, 0));
+        for (uint32_t k = 0; k < lanes; ++k) HIPCHK(ctx, hipStreamWaitEvent(ctx->ws[(lane_base + k) % pool].stream, ctx->fork, 0));
+    } else {
+        // one work set, used directly on the caller's stream: order this frame after the set's previous user, which may
+        // have been queued on another stream
+        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ws[0].done, 0));
     }
 
     uint32_t blocks_done = 0;
@@ -827,7 +847,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     uint32_t batches_run = 0;
     for (uint32_t bi = 0; bi < n_batches; ++bi) {
         if (cancel_flag && *cancel_flag) { result = TRR_ERR_CANCELLED; break; }   // render.rs:113
-        trr_ctx::WorkSet& w = ctx->ws[bi % lanes];
+        trr_ctx::WorkSet& w = ctx->ws[(lane_base + bi % lanes) % pool];
         hipStream_t s_ = forked ? w.stream : st;
         uint32_t* cw = (uint32_t*)w.counters.p;
         unsigned long long* kc = (unsigned long long*)((char*)w.counters.p + CW_WORDS * 4);
@@ -900,9 +920,12 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     }
     if (forked) {   // join
         for (uint32_t k = 0; k < lanes; ++k) {
-            HIPCHK(ctx, hipEventRecord(ctx->ws[k].done, ctx->ws[k].stream));
-            HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ws[k].done, 0));
+            trr_ctx::WorkSet& w = ctx->ws[(lane_base + k) % pool];
+            HIPCHK(ctx, hipEventRecord(w.done, w.stream));
+            HIPCHK(ctx, hipStreamWaitEvent(st, w.done, 0));
         }
+    } else {
+        HIPCHK(ctx, hipEventRecord(ctx->ws[0].done, st));
     }
     if (stats) {
         trr_ctx::PendingStats f;

@@ -127,7 +127,7 @@ class ShardedRenderer:
         rs.wait_event(sl["consumed"])          # the strip's previous contents have been gathered / assembled
         with torch.cuda.stream(rs):
             self.rt.render_shard_device(self.rank, self.world, sl["strip"].data_ptr(), self.sb, stream=rs.cuda_stream,
-                                        stats=stats, counters=counters, defer_stats=defer_stats)
+                                        stats=stats, counters=counters, defer_stats=defer_stats, pipelined=self.n_slots >= 2)
             sl["rendered"].record(rs)
         cs = self.comm_stream
         cs.wait_event(sl["rendered"])

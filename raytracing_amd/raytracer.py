@@ -222,11 +222,14 @@ class Raytracer:
         return int(N.lib().trr_strip_bytes(self.width, self.height, int(n_shards)))
 
     def render_shard_device(self, shard: int, n_shards: int, strip_ptr: int, strip_bytes: int, stream: Optional[int] = None,
-                            counters: bool = False, stats: Optional[N.Stats] = None, defer_stats: bool = False):
+                            counters: bool = False, stats: Optional[N.Stats] = None, defer_stats: bool = False,
+                            pipelined: bool = False):
         """This rank's blocks (block id % n_shards == shard) into a device strip; asynchronous on ``stream``
         unless ``stats`` is given without ``defer_stats`` (statistics need the queue counters back).  With
-        ``defer_stats`` the call stays asynchronous and ``stats`` is filled by ``Context.collect_stats()``."""
-        flags = (N.TRR_FLAG_COUNTERS if counters else 0) | (N.TRR_FLAG_DEFER_STATS if (defer_stats and stats is not None) else 0)
+        ``defer_stats`` the call stays asynchronous and ``stats`` is filled by ``Context.collect_stats()``.  ``pipelined``: the
+        caller keeps two frames in flight on alternating streams and strips (TRR_FLAG_PIPELINED)."""
+        flags = ((N.TRR_FLAG_COUNTERS if counters else 0) | (N.TRR_FLAG_DEFER_STATS if (defer_stats and stats is not None) else 0) |
+                 (N.TRR_FLAG_PIPELINED if pipelined else 0))
         rc = N.lib().trr_render_shard_device(self.ctx.handle, self._scene, self.delta, self.max_depth,
                                              flags, int(shard), int(n_shards),
                                              strip_ptr, int(strip_bytes), stream, None, None, None,
