@@ -691,7 +691,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     const uint64_t per_sample = 32 /*hits*/ + 4ull * LEVEL_PLANES * std::max(1u, max_depth) + 12 + 1 +
                                 4ull * L * std::max(1u, max_depth) + 32ull * L + 64;
     const uint64_t spb = (uint64_t)bpix * spp;
-    // Batch count (measured on MI355X, scratch sweeps of round 1): few, large batches -- every persistent launch pays a
+    // Batch count (measured on MI355X, scripts/experiments/sweep_batches.py): few, large batches -- every persistent launch pays a
     // ramp-up and a tail of fixed length -- but at least two, on two lanes, so that one batch's tails and small deep-level
     // launches overlap the other's bulk; three lanes once there are four or more batches.  An odd batch per lane keeps
     // the lanes out of lock-step.  TRR_LANES / TRR_BATCHES_PER_LANE / TRR_BATCHES override (experiments).
