@@ -142,6 +142,33 @@ const char* trr_last_error(const trr_ctx* ctx);
 int trr_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_objects,
                      const trr_image_rgb8* textures, uint32_t n_textures, trr_scene** out);
 void trr_scene_destroy(trr_scene* scene);
+
+/* The same with the BVH built where `build` says.  The reference rebuilds an object's Bvh on the CPU whenever the UI
+ * adds an object (object.rs:156 via ui/properties.rs:307-415); TRR_BUILD_DEVICE does the whole flattening on the GPU
+ * (Morton keys, radix sort, radix tree, box fit, 4-wide collapse: tens of milliseconds for 10 M triangles instead of
+ * seconds), at the price of a tree that traces slower than the host's SAH tree.  Both builders produce the same
+ * triangle / interpolation records, and -- because the closest hit is a min over every triangle whose own box the ray
+ * passes (object.rs:191-206), whatever the tree -- the same image. */
+#define TRR_BUILD_HOST 0u     /* binned-SAH build on the host cores (what trr_scene_create does) */
+#define TRR_BUILD_DEVICE 1u   /* LBVH build on the GPU */
+int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_objects,
+                        const trr_image_rgb8* textures, uint32_t n_textures, uint32_t build, trr_scene** out);
+
+/* What the upload produced (no counterpart in the reference, whose Bvh is opaque). */
+typedef struct trr_scene_info {
+    uint64_t n_triangles;        /* rows of all objects' triangle arrays */
+    uint64_t n_triangles_live;   /* of those, in the tree (|ab x ac| > 0, triangle.rs:56) */
+    uint64_t n_nodes;            /* 128-B 4-wide nodes */
+    uint32_t bvh_depth;          /* levels of the deepest object tree (root = 1) */
+    uint32_t build;              /* TRR_BUILD_* */
+    double ms_build;             /* wall time of the flattening + BVH build + upload */
+} trr_scene_info;
+int trr_scene_get_info(const trr_scene* scene, trr_scene_info* out);
+/* Diagnostic: downloads the node and triangle arrays and checks the tree on the host -- every live triangle in exactly
+ * one leaf, every child box containing the reference's own box (triangle.rs:88-95) of every triangle below it, all
+ * references in range.  TRR_OK or TRR_ERR_INVALID with the first violation in trr_last_error(). */
+int trr_scene_validate(trr_scene* scene);
+
 /* Cheap per-render state the UI edits between renders (ui/properties.rs). */
 int trr_scene_set_instances(trr_scene* scene, const float* transforms, const float* inverses, uint32_t n_objects);
 int trr_scene_set_lights(trr_scene* scene, const trr_light* lights, uint32_t n_lights);

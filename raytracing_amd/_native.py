@@ -69,11 +69,23 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class SceneInfo(C.Structure):
+    _fields_ = [("n_triangles", C.c_uint64), ("n_triangles_live", C.c_uint64), ("n_nodes", C.c_uint64),
+                ("bvh_depth", C.c_uint32), ("build", C.c_uint32), ("ms_build", C.c_double)]
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+TRR_BUILD_HOST = 0
+TRR_BUILD_DEVICE = 1
+
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)
 
 # every symbol include/trayracer_hip.h declares
 EXPORTS = [
-    "trr_create", "trr_destroy", "trr_last_error", "trr_scene_create", "trr_scene_destroy", "trr_scene_set_instances",
+    "trr_create", "trr_destroy", "trr_last_error", "trr_scene_create", "trr_scene_create_ex", "trr_scene_get_info",
+    "trr_scene_validate", "trr_scene_destroy", "trr_scene_set_instances",
     "trr_scene_set_lights", "trr_scene_set_settings", "trr_scene_set_camera", "trr_render", "trr_render_shard_device",
     "trr_strip_bytes", "trr_assemble_device", "trr_synchronize", "trr_collect_stats", "trr_object_matrices", "trr_camera_ray", "trr_version",
 ]
@@ -116,6 +128,12 @@ def lib() -> C.CDLL:
     L.trr_destroy.argtypes = [vp]
     L.trr_scene_create.restype = i32
     L.trr_scene_create.argtypes = [vp, vp, u32, vp, u32, C.POINTER(vp)]
+    L.trr_scene_create_ex.restype = i32
+    L.trr_scene_create_ex.argtypes = [vp, vp, u32, vp, u32, u32, C.POINTER(vp)]
+    L.trr_scene_get_info.restype = i32
+    L.trr_scene_get_info.argtypes = [vp, vp]
+    L.trr_scene_validate.restype = i32
+    L.trr_scene_validate.argtypes = [vp]
     L.trr_scene_destroy.restype = None
     L.trr_scene_destroy.argtypes = [vp]
     L.trr_scene_set_instances.restype = i32

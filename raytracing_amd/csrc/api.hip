@@ -19,6 +19,7 @@
 
 #include "../../include/trayracer_hip.h"
 #include "bvh.h"
+#include "build_device.h"
 #include "device_types.h"
 #include "launch.h"
 
@@ -96,6 +97,8 @@ struct trr_scene {
     uint32_t n_objs = 0, n_lights = 0, n_mats = 0, n_tex = 0;
     uint64_t n_nodes = 0, n_tris_total = 0, n_tris_live = 0;
     uint32_t bvh_depth = 0;
+    uint32_t build = TRR_BUILD_HOST;
+    double ms_build = 0.0;
     trr_settings settings{};
     bool have_settings = false;
     uint32_t sky_w = 0, sky_h = 0;
@@ -337,12 +340,90 @@ static void fill_obj_matrices(ObjRec& o, const float* fwd_cm, const float* inv_c
         }
 }
 
+// TRR_BUILD_DEVICE: every object's tree is built on the GPU (build_device.hip) into arrays of its own, which are then
+// packed behind one another.  sc->mats is already on the device; fills sc->nodes / tris / interp / h_objs and the counts.
+static int build_scene_device(trr_ctx* ctx, trr_scene* sc, const trr_object_desc* objects, uint32_t n_objects,
+                              const std::vector<uint32_t>& mat_bases) {
+    std::vector<DeviceBuildOut> parts(n_objects);
+    auto free_parts = [&]() {
+        for (DeviceBuildOut& p : parts) {
+            if (p.nodes) (void)hipFree(p.nodes);
+            if (p.tris) (void)hipFree(p.tris);
+            p.nodes = nullptr;
+            p.tris = nullptr;
+        }
+    };
+    int rc = ensure(ctx, sc->interp, (size_t)sc->n_tris_total * sizeof(InterpRec));
+    if (rc != TRR_OK) return rc;
+    uint64_t node_base = 0, slot_base = 0, interp_base = 0;
+    uint32_t depth_max = 0;
+    sc->h_objs.assign(n_objects, ObjRec{});
+    for (uint32_t oi = 0; oi < n_objects; ++oi) {
+        const trr_object_desc& d = objects[oi];
+        // leaf references hold the first triangle slot in 29 bits (see trr_scene_create_ex)
+        if (slot_base + d.n_triangles >= (1ull << 29) - 1 || node_base + d.n_triangles >= (1ull << 31)) {
+            free_parts();
+            return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: more than 2^29 - 2 triangles in one scene");
+        }
+        std::string msg;
+        hipError_t e = build_object_device(d.triangles, d.material_index, d.n_triangles, static_cast<const MatRec*>(sc->mats.p),
+                                           mat_bases[oi], d.n_materials, (uint32_t)node_base, (uint32_t)slot_base,
+                                           static_cast<InterpRec*>(sc->interp.p) + interp_base, ctx->stream, &parts[oi], &msg);
+        if (e != hipSuccess) {
+            free_parts();
+            return fail(ctx, e == hipErrorOutOfMemory ? TRR_ERR_NOMEM : TRR_ERR_DEVICE, "device BVH build of object " + std::to_string(oi) + ": " + msg);
+        }
+        ObjRec& o = sc->h_objs[oi];
+        fill_obj_matrices(o, d.transform, d.inverse);
+        o.root = parts[oi].root_ref;
+        o.tri_base = (uint32_t)interp_base;
+        o.n_tris = d.n_triangles;
+        o.flags = (d.n_triangles == 1) ? 1u : 0u;   // [crate] a root Leaf is returned by traverse() without a box test
+        o.slack_abs = 1.0e-4f * parts[oi].maxabs;
+        depth_max = std::max(depth_max, parts[oi].depth);
+        node_base += parts[oi].n_nodes;
+        slot_base += parts[oi].n_live;
+        interp_base += d.n_triangles;
+    }
+    if ((rc = ensure(ctx, sc->nodes, (size_t)node_base * sizeof(Node4))) != TRR_OK ||
+        (rc = ensure(ctx, sc->tris, (size_t)slot_base * sizeof(TriRec))) != TRR_OK) {
+        free_parts();
+        return rc;
+    }
+    uint64_t nb = 0, sb = 0;
+    hipError_t e = hipSuccess;
+    for (uint32_t oi = 0; oi < n_objects && e == hipSuccess; ++oi) {
+        const DeviceBuildOut& p = parts[oi];
+        if (p.n_nodes)
+            e = hipMemcpyAsync(static_cast<Node4*>(sc->nodes.p) + nb, p.nodes, (size_t)p.n_nodes * sizeof(Node4), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess && p.n_live)
+            e = hipMemcpyAsync(static_cast<TriRec*>(sc->tris.p) + sb, p.tris, (size_t)p.n_live * sizeof(TriRec), hipMemcpyDeviceToDevice, ctx->stream);
+        nb += p.n_nodes;
+        sb += p.n_live;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    free_parts();
+    if (e != hipSuccess) return fail(ctx, TRR_ERR_DEVICE, std::string("device BVH build: packing the objects: ") + hipGetErrorString(e));
+    sc->n_nodes = node_base;
+    sc->n_tris_live = slot_base;
+    sc->bvh_depth = depth_max;
+    return TRR_OK;
+}
+
 int trr_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_objects, const trr_image_rgb8* textures,
                      uint32_t n_textures, trr_scene** out) {
+    return trr_scene_create_ex(ctx, objects, n_objects, textures, n_textures, TRR_BUILD_HOST, out);
+}
+
+int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_objects, const trr_image_rgb8* textures,
+                        uint32_t n_textures, uint32_t build, trr_scene** out) {
     if (!ctx || !out) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: NULL argument");
     *out = nullptr;
     if (n_objects && !objects) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: objects is NULL");
+    if (n_textures && !textures) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: textures is NULL");
+    if (build != TRR_BUILD_HOST && build != TRR_BUILD_DEVICE) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create_ex: unknown build mode");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    const auto t_start = std::chrono::steady_clock::now();
 
     std::vector<Node4> nodes;
     std::vector<TriRec> tris;
@@ -353,12 +434,13 @@ int trr_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_ob
     uint64_t n_total = 0;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
 
+    // material table of all objects (object-local indices become global ones: mat_bases[object] + index)
+    std::vector<uint32_t> mat_bases(n_objects, 0);
     for (uint32_t oi = 0; oi < n_objects; ++oi) {
         const trr_object_desc& d = objects[oi];
         if (d.n_triangles && !d.triangles) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: object without triangles pointer");
         if (d.n_materials && !d.materials) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: object without materials pointer");
-        const uint32_t nt = d.n_triangles;
-        const uint32_t mat_base = (uint32_t)mats.size();
+        mat_bases[oi] = (uint32_t)mats.size();
         for (uint32_t m = 0; m < d.n_materials; ++m) {
             const trr_material_desc& s = d.materials[m];
             MatRec r{};
@@ -368,6 +450,13 @@ int trr_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_ob
             r.flags = s.flags;
             mats.push_back(r);
         }
+        n_total += d.n_triangles;
+    }
+
+    for (uint32_t oi = 0; build == TRR_BUILD_HOST && oi < n_objects; ++oi) {
+        const trr_object_desc& d = objects[oi];
+        const uint32_t nt = d.n_triangles;
+        const uint32_t mat_base = mat_bases[oi];
         // per-triangle: normal/len (triangle.rs:54-56), own box (triangle.rs:88-95), interpolation record
         std::vector<TriRec> recs(nt);
         std::vector<Box3> boxes(nt);
@@ -460,7 +549,6 @@ int trr_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_ob
         o.flags = (nt == 1) ? 1u : 0u;   // [crate] a root Leaf is returned by traverse() without a box test
         o.slack_abs = 1.0e-4f * maxabs;
         depth_max = std::max(depth_max, br.max_depth);
-        n_total += nt;
     }
     // leaf references hold the first triangle slot in 29 bits, and the two highest 32-bit values are REF_EMPTY and the
     // trace kernel's "idle lane" marker; node indices must stay below REF_LEAF
@@ -492,17 +580,108 @@ int trr_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_ob
         texels.insert(texels.end(), textures[t].rgb, textures[t].rgb + nb);
     }
     int rc = TRR_OK;
-    if ((rc = upload(ctx, sc->nodes, nodes.data(), nodes.size() * sizeof(Node4))) != TRR_OK ||
-        (rc = upload(ctx, sc->tris, tris.data(), tris.size() * sizeof(TriRec))) != TRR_OK ||
-        (rc = upload(ctx, sc->interp, interp.data(), interp.size() * sizeof(InterpRec))) != TRR_OK ||
-        (rc = upload(ctx, sc->objs, objs.data(), objs.size() * sizeof(ObjRec))) != TRR_OK ||
-        (rc = upload(ctx, sc->mats, mats.data(), mats.size() * sizeof(MatRec))) != TRR_OK ||
+    if ((rc = upload(ctx, sc->mats, mats.data(), mats.size() * sizeof(MatRec))) != TRR_OK ||
         (rc = upload(ctx, sc->texs, texs.data(), texs.size() * sizeof(TexRec))) != TRR_OK ||
         (rc = upload(ctx, sc->texels, texels.data(), texels.size())) != TRR_OK) {
         trr_scene_destroy(sc);
         return rc;
     }
+    if (build == TRR_BUILD_DEVICE) {
+        rc = build_scene_device(ctx, sc, objects, n_objects, mat_bases);
+    } else {
+        if ((rc = upload(ctx, sc->nodes, nodes.data(), nodes.size() * sizeof(Node4))) == TRR_OK &&
+            (rc = upload(ctx, sc->tris, tris.data(), tris.size() * sizeof(TriRec))) == TRR_OK)
+            rc = upload(ctx, sc->interp, interp.data(), interp.size() * sizeof(InterpRec));
+    }
+    if (rc == TRR_OK) rc = upload(ctx, sc->objs, sc->h_objs.data(), sc->h_objs.size() * sizeof(ObjRec));
+    if (rc != TRR_OK) {
+        trr_scene_destroy(sc);
+        return rc;
+    }
+    sc->build = build;
+    sc->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     *out = sc;
+    return TRR_OK;
+}
+
+int trr_scene_get_info(const trr_scene* sc, trr_scene_info* out) {
+    if (!sc || !out) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_get_info: NULL argument");
+    out->n_triangles = sc->n_tris_total;
+    out->n_triangles_live = sc->n_tris_live;
+    out->n_nodes = sc->n_nodes;
+    out->bvh_depth = sc->bvh_depth;
+    out->build = sc->build;
+    out->ms_build = sc->ms_build;
+    return TRR_OK;
+}
+
+int trr_scene_validate(trr_scene* sc) {
+    if (!sc) return fail(nullptr, TRR_ERR_INVALID, "trr_scene_validate: NULL argument");
+    trr_ctx* ctx = sc->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<Node4> nodes(sc->n_nodes);
+    std::vector<TriRec> tris(sc->n_tris_live);
+    if (!nodes.empty()) HIPCHK(ctx, hipMemcpy(nodes.data(), sc->nodes.p, nodes.size() * sizeof(Node4), hipMemcpyDeviceToHost));
+    if (!tris.empty()) HIPCHK(ctx, hipMemcpy(tris.data(), sc->tris.p, tris.size() * sizeof(TriRec), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> node_seen(nodes.size(), 0), slot_seen(tris.size(), 0);
+    auto bad = [&](uint32_t oi, const std::string& what) {
+        return fail(ctx, TRR_ERR_INVALID, "trr_scene_validate: object " + std::to_string(oi) + ": " + what);
+    };
+    // a >= b unless either is NaN (NaN coordinates make no promise in either builder)
+    auto ge = [](float a, float b) { return !(a < b); };
+    uint32_t depth_seen = 0;
+    for (uint32_t oi = 0; oi < sc->n_objs; ++oi) {
+        const ObjRec& o = sc->h_objs[oi];
+        std::vector<uint8_t> tri_seen(o.n_tris, 0);
+        struct Item { uint32_t ref; Box3 box; bool has_box; uint32_t depth; };
+        std::vector<Item> stack;
+        stack.push_back(Item{o.root, Box3{}, false, 1});
+        while (!stack.empty()) {
+            Item it = stack.back();
+            stack.pop_back();
+            if (it.ref == REF_EMPTY) continue;
+            if (it.ref & REF_LEAF) {
+                uint32_t first = (it.ref & 0x7FFFFFFFu) >> 2, cnt = (it.ref & 3u) + 1u;
+                if ((uint64_t)first + cnt > tris.size()) return bad(oi, "leaf slots out of range");
+                for (uint32_t s = first; s < first + cnt; ++s) {
+                    if (slot_seen[s]++) return bad(oi, "triangle slot " + std::to_string(s) + " is in two leaves");
+                    const TriRec& r = tris[s];
+                    if (r.tri_id >= o.n_tris) return bad(oi, "triangle id out of range in slot " + std::to_string(s));
+                    if (tri_seen[r.tri_id]++) return bad(oi, "triangle " + std::to_string(r.tri_id) + " is in two slots");
+                    if (!it.has_box) continue;
+                    const float a[3] = {r.ax, r.ay, r.az}, b[3] = {r.bx, r.by, r.bz}, c[3] = {r.cx, r.cy, r.cz};
+                    for (int k = 0; k < 3; ++k) {   // triangle.rs:88-95
+                        float c2 = c[k] + 0.0001f;
+                        float lo = std::fmin(std::fmin(a[k], b[k]), c2), hi = std::fmax(std::fmax(a[k], b[k]), c2);
+                        if (!ge(lo, it.box.lo[k]) || !ge(it.box.hi[k], hi))
+                            return bad(oi, "leaf box does not contain triangle " + std::to_string(r.tri_id));
+                    }
+                }
+                continue;
+            }
+            if (it.ref >= nodes.size()) return bad(oi, "node reference out of range");
+            if (node_seen[it.ref]++) return bad(oi, "node " + std::to_string(it.ref) + " has two parents");
+            depth_seen = std::max(depth_seen, it.depth);
+            if (it.depth > 4096) return bad(oi, "tree deeper than 4096 levels");
+            const Node4& nd = nodes[it.ref];
+            for (int k = 0; k < 4; ++k) {
+                if (nd.child[k] == REF_EMPTY) continue;
+                Box3 bx{{nd.lox[k], nd.loy[k], nd.loz[k]}, {nd.hix[k], nd.hiy[k], nd.hiz[k]}};
+                if (it.has_box)
+                    for (int a = 0; a < 3; ++a)
+                        if (!ge(bx.lo[a], it.box.lo[a]) || !ge(it.box.hi[a], bx.hi[a]))
+                            return bad(oi, "child box of node " + std::to_string(it.ref) + " sticks out of its parent's");
+                stack.push_back(Item{nd.child[k], bx, true, it.depth + 1});
+            }
+        }
+    }
+    for (size_t s = 0; s < slot_seen.size(); ++s)
+        if (!slot_seen[s]) return fail(ctx, TRR_ERR_INVALID, "trr_scene_validate: triangle slot " + std::to_string(s) + " is in no leaf");
+    for (size_t i = 0; i < node_seen.size(); ++i)
+        if (!node_seen[i]) return fail(ctx, TRR_ERR_INVALID, "trr_scene_validate: node " + std::to_string(i) + " is unreachable");
+    if (depth_seen > sc->bvh_depth)
+        return fail(ctx, TRR_ERR_INVALID, "trr_scene_validate: tree depth " + std::to_string(depth_seen) + " exceeds the recorded " +
+                                              std::to_string(sc->bvh_depth));
     return TRR_OK;
 }
 

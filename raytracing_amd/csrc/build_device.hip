@@ -1,0 +1,430 @@
+// build_device.hip -- BVH4 build on the GPU for gfx950.
+//
+// Stands in, like bvh.cpp, for bvh::Bvh::build (reference call site: src/scene/object.rs:156) and for the per-triangle
+// values Triangle::intersect / Triangle::aabb recompute on every call (src/scene/triangle.rs:54-56, 88-95).  The tree's
+// shape is free (bvh.h); what has to hold is (i) every child box contains the reference's own box of every triangle
+// below it and (ii) the TriRec / InterpRec values equal the host builder's bit for bit -- both are checked by
+// trr_scene_validate and by the parity tests, which render the same scene with both builders.
+//
+// Pipeline (all HBM-bound, one pass each over n triangles): prep (raw 96-B triangles -> box, InterpRec, live flag,
+// centroid bounds) -> 63-bit Morton keys -> hipCUB radix sort of (key, triangle) -> Karras radix tree -> bottom-up box
+// fit -> level-by-level collapse into 128-B 4-wide nodes -> gather of the 64-B TriRecs into leaf order.
+#include "build_device.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#define TRR_HD __host__ __device__
+#include "lbvh_core.h"
+
+namespace trr {
+namespace {
+
+constexpr int BT = 256;
+
+// order-preserving map float -> uint32 (for atomicMin / atomicMax on floats of either sign)
+__host__ __device__ inline uint32_t f2ord(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+struct Globals {            // one small device record per build, zero-initialised except cmin
+    uint32_t cmin[3];       // f2ord of the centroid bounds of the live triangles
+    uint32_t cmax[3];
+    uint32_t maxabs;        // bits of the largest finite |coordinate| (non-negative floats order like their bits)
+    uint32_t n_live;
+    uint32_t n_big;         // inner nodes of the binary tree over more than MAX_LEAF triangles (bound on the 4-wide nodes)
+    uint32_t n_nodes;       // 4-wide nodes allocated so far
+    uint32_t q_count[2];    // items in the two collapse queues
+};
+
+struct Tri9 {
+    float a[3], b[3], c[3];
+};
+
+__device__ inline void load_raw(const float* raw, uint32_t t, float f[24]) {
+    const float4* p = reinterpret_cast<const float4*>(raw + (size_t)t * 24);   // 96-B rows of a hipMalloc'd array
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float4 v = p[k];
+        f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
+    }
+}
+
+// triangle.rs:54-56: n = (ab x ac) / |ab x ac|, len = |ab x ac|, with the operation order of api.hip's hcross/hdot/hnorm
+__device__ inline void normal_of(const float f[24], float n[3], float* len) {
+    float abx = f[3] - f[0], aby = f[4] - f[1], abz = f[5] - f[2];
+    float acx = f[6] - f[0], acy = f[7] - f[1], acz = f[8] - f[2];
+    float cx = aby * acz - abz * acy, cy = abz * acx - abx * acz, cz = abx * acy - aby * acx;
+    float l = sqrtf((cx * cx + cy * cy) + cz * cz);
+    n[0] = cx / l; n[1] = cy / l; n[2] = cz / l;
+    *len = l;
+}
+
+__device__ inline float wave_min(float v) {
+    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline float wave_max(float v) {
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ void __launch_bounds__(BT) k_prep(const float* __restrict__ raw, uint32_t nt, InterpRec* __restrict__ interp,
+                                             Box3* __restrict__ boxes, uint8_t* __restrict__ live, Globals* g) {
+    const uint32_t t = blockIdx.x * BT + threadIdx.x;
+    const bool valid = t < nt;
+    const float inf = __builtin_inff();
+    float cmin[3] = {inf, inf, inf}, cmax[3] = {-inf, -inf, -inf};
+    float ma = 0.0f;
+    bool is_live = false;
+    if (valid) {
+        float f[24];
+        load_raw(raw, t, f);
+        float n[3], len;
+        normal_of(f, n, &len);
+        is_live = !(len <= 0.0f);   // |ab x ac| == 0 can never be hit for any delta >= 0 (triangle.rs:56)
+        // triangle.rs:88-95: Aabb::empty().grow(a).grow(b).grow(c + 1e-4)
+        Box3 bx;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float c2 = f[6 + k] + 0.0001f;
+            bx.lo[k] = fminf(fminf(f[k], f[3 + k]), c2);
+            bx.hi[k] = fmaxf(fmaxf(f[k], f[3 + k]), c2);
+        }
+        boxes[t] = bx;
+        live[t] = is_live ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float v = fabsf(f[k]);
+            if ((v - v == 0.0f) && v > ma) ma = v;
+        }
+        if (is_live) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float c = 0.5f * bx.lo[k] + 0.5f * bx.hi[k];
+                if (!(c - c == 0.0f)) c = 0.0f;   // NaN / infinite vertices must not poison the keys
+                cmin[k] = c; cmax[k] = c;
+            }
+        }
+        float4* ip = reinterpret_cast<float4*>(interp + t);
+        ip[0] = make_float4(f[9], f[10], f[11], f[12]);     // na, nb.x
+        ip[1] = make_float4(f[13], f[14], f[15], f[16]);    // nb.yz, nc.xy
+        ip[2] = make_float4(f[17], f[18], f[19], f[20]);    // nc.z, uva, uvb.x
+        ip[3] = make_float4(f[21], f[22], f[23], 0.0f);     // uvb.y, uvc, pad
+    }
+    // every lane of the wavefront takes part in the reductions
+    const unsigned long long lm = __ballot(is_live);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { cmin[k] = wave_min(cmin[k]); cmax[k] = wave_max(cmax[k]); }
+    ma = wave_max(ma);
+    if ((threadIdx.x & 63) == 0) {
+        if (lm) {
+            for (int k = 0; k < 3; ++k) {
+                atomicMin(&g->cmin[k], f2ord(cmin[k]));
+                atomicMax(&g->cmax[k], f2ord(cmax[k]));
+            }
+            atomicAdd(&g->n_live, (uint32_t)__popcll(lm));
+        }
+        if (ma > 0.0f) atomicMax(&g->maxabs, __float_as_uint(ma));
+    }
+}
+
+__global__ void __launch_bounds__(BT) k_keys(const Box3* __restrict__ boxes, const uint8_t* __restrict__ live, uint32_t nt,
+                                             const Globals* g, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t t = blockIdx.x * BT + threadIdx.x;
+    if (t >= nt) return;
+    uint64_t key = lbvh::KEY_DEAD;
+    if (live[t]) {
+        float lo[3], ext[3], c[3];
+        const Box3 bx = boxes[t];
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = ord2f(g->cmin[k]);
+            ext[k] = ord2f(g->cmax[k]) - lo[k];
+            c[k] = 0.5f * bx.lo[k] + 0.5f * bx.hi[k];
+            if (!(c[k] - c[k] == 0.0f)) c[k] = 0.0f;
+        }
+        key = lbvh::morton63(c, lo, ext);
+    }
+    keys[t] = key;
+    vals[t] = t;
+}
+
+__global__ void __launch_bounds__(BT) k_hier(const uint64_t* __restrict__ keys, uint32_t n, lbvh::Tree tree, Globals* g) {
+    const uint32_t i = blockIdx.x * BT + threadIdx.x;
+    bool big = false;
+    if (i + 1 < n) {
+        lbvh::build_inner(keys, (int64_t)n, (int64_t)i, tree);
+        big = tree.last[i] - tree.first[i] + 1u > lbvh::MAX_LEAF;
+    }
+    const unsigned long long m = __ballot(big);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&g->n_big, (uint32_t)__popcll(m));
+}
+
+__device__ inline Box3 load_box_coherent(const Box3* p) {
+    // written by another workgroup during this launch: read past the (non-coherent) vector L1
+    Box3 r;
+    for (int k = 0; k < 3; ++k) {
+        r.lo[k] = __hip_atomic_load(&p->lo[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.hi[k] = __hip_atomic_load(&p->hi[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return r;
+}
+
+// One thread per leaf walks towards the root; at every inner node the first arrival stops, the second one (which
+// therefore sees both children finished) writes the node's box and goes on.  Every thread ends after at most
+// tree-depth steps; nothing waits.
+__global__ void __launch_bounds__(BT) k_fit(uint32_t n, lbvh::Tree tree, uint32_t* __restrict__ arrived) {
+    const uint32_t s = blockIdx.x * BT + threadIdx.x;
+    if (s >= n) return;
+    Box3 box = tree.boxes[tree.val[s]];
+    uint32_t me = lbvh::LEAF_BIT | s;
+    uint32_t p = tree.parent_leaf[s];
+    while (p != lbvh::NONE) {
+        __threadfence();                                   // my box (if any) is visible before the arrival count
+        if (atomicAdd(&arrived[p], 1u) == 0u) return;
+        __threadfence();
+        const uint32_t l = tree.child_l[p], r = tree.child_r[p];
+        const uint32_t sib = (l == me) ? r : l;
+        const Box3 sb = (sib & lbvh::LEAF_BIT) ? tree.boxes[tree.val[sib & ~lbvh::LEAF_BIT]] : load_box_coherent(&tree.ibox[sib]);
+        box = lbvh::box_union(box, sb);
+        tree.ibox[p] = box;
+        me = p;
+        p = tree.parent_inner[p];
+    }
+}
+
+// One level of the top-down collapse: every queue item (binary inner node, index of its 4-wide node) writes its node
+// and queues the children that are inner nodes of the 4-wide tree.
+__global__ void __launch_bounds__(BT) k_collapse(const uint2* __restrict__ q_in, uint32_t n_in, uint2* __restrict__ q_out,
+                                                 uint32_t q_cap, uint32_t which_out, lbvh::Tree tree, Node4* __restrict__ nodes,
+                                                 uint32_t node_cap, uint32_t node_base, uint32_t slot_base, Globals* g) {
+    const uint32_t i = blockIdx.x * BT + threadIdx.x;
+    if (i >= n_in) return;
+    const uint2 item = q_in[i];
+    uint32_t kids[4];
+    const int nk = lbvh::collapse_children(tree, item.x, kids);
+    Node4 nd;
+    for (int k = 0; k < 4; ++k) {
+        nd.pad[k] = 0;
+        if (k >= nk) { lbvh::node4_set_empty(nd, k); continue; }
+        lbvh::node4_set_box(nd, k, lbvh::ref_box(tree, kids[k]));
+        if (lbvh::leaf_like(tree, kids[k])) {
+            nd.child[k] = lbvh::leaf_ref_of(tree, kids[k], slot_base);
+        } else {
+            const uint32_t idx = atomicAdd(&g->n_nodes, 1u);
+            const uint32_t qp = atomicAdd(&g->q_count[which_out], 1u);
+            if (idx < node_cap && qp < q_cap) {
+                q_out[qp] = make_uint2(kids[k], idx);
+                nd.child[k] = node_base + idx;
+            } else {
+                nd.child[k] = REF_EMPTY;   // cannot happen (both are sized by n_big); the host checks the counters
+            }
+        }
+    }
+    if (item.y < node_cap) {
+        float4* dst = reinterpret_cast<float4*>(nodes + item.y);
+        const float4* src = reinterpret_cast<const float4*>(&nd);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = src[k];
+    }
+}
+
+__global__ void __launch_bounds__(BT) k_gather(const float* __restrict__ raw, const int32_t* __restrict__ matidx,
+                                               const uint32_t* __restrict__ vals, uint32_t n_live, const MatRec* __restrict__ mats,
+                                               uint32_t mat_base, uint32_t n_mats_obj, TriRec* __restrict__ out) {
+    const uint32_t s = blockIdx.x * BT + threadIdx.x;
+    if (s >= n_live) return;
+    const uint32_t t = vals[s];
+    float f[24];
+    load_raw(raw, t, f);
+    float n[3], len;
+    normal_of(f, n, &len);
+    int32_t mi = matidx ? matidx[t] : -1;
+    int32_t mat = (mi >= 0 && (uint32_t)mi < n_mats_obj) ? (int32_t)(mat_base + (uint32_t)mi) : -1;
+    uint32_t flags = 0;
+    if (mat >= 0) {
+        int il = mats[mat].illum;
+        if (il == 6 || il == 7) flags |= 1u;   // material.rs:51-53
+    }
+    float4* dst = reinterpret_cast<float4*>(out + s);
+    dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+    dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+    dst[2] = make_float4(f[8], n[0], n[1], n[2]);
+    dst[3] = make_float4(__uint_as_float(t), __int_as_float(mat), len, __uint_as_float(flags));
+}
+
+struct Tmp {   // device allocations of one build, freed on every exit path
+    std::vector<void*> ptrs;
+    ~Tmp() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T>
+    hipError_t get(T** out, size_t count) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return e;
+    }
+    void keep(void* p) {   // ownership passes to the caller
+        for (auto& q : ptrs) if (q == p) q = nullptr;
+    }
+};
+
+inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + BT - 1) / BT); }
+
+}   // namespace
+
+#define BCK(expr)                                                                                 \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e__);                   \
+            return e__;                                                                           \
+        }                                                                                         \
+    } while (0)
+
+hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uint32_t nt, const MatRec* d_mats, uint32_t mat_base,
+                               uint32_t n_mats_obj, uint32_t node_base, uint32_t slot_base, InterpRec* d_interp, hipStream_t stream,
+                               DeviceBuildOut* out, std::string* err) {
+    *out = DeviceBuildOut{};
+    if (nt == 0) return hipSuccess;
+    Tmp tmp;
+    float* raw = nullptr;
+    int32_t* matidx = nullptr;
+    Box3* boxes = nullptr;
+    uint8_t* live = nullptr;
+    Globals* g = nullptr;
+    uint64_t *keys_a = nullptr, *keys_b = nullptr;
+    uint32_t *vals_a = nullptr, *vals_b = nullptr;
+    BCK(tmp.get(&raw, (size_t)nt * 24));
+    BCK(tmp.get(&boxes, nt));
+    BCK(tmp.get(&live, nt));
+    BCK(tmp.get(&g, 1));
+    BCK(tmp.get(&keys_a, nt));
+    BCK(tmp.get(&keys_b, nt));
+    BCK(tmp.get(&vals_a, nt));
+    BCK(tmp.get(&vals_b, nt));
+    BCK(hipMemcpyAsync(raw, h_tris, (size_t)nt * 24 * sizeof(float), hipMemcpyHostToDevice, stream));
+    if (h_matidx) {
+        BCK(tmp.get(&matidx, nt));
+        BCK(hipMemcpyAsync(matidx, h_matidx, (size_t)nt * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    }
+    Globals h{};
+    for (int k = 0; k < 3; ++k) { h.cmin[k] = 0xFFFFFFFFu; h.cmax[k] = 0u; }
+    BCK(hipMemcpyAsync(g, &h, sizeof h, hipMemcpyHostToDevice, stream));
+
+    hipLaunchKernelGGL(k_prep, dim3(blocks_for(nt)), dim3(BT), 0, stream, raw, nt, d_interp, boxes, live, g);
+    BCK(hipGetLastError());
+    hipLaunchKernelGGL(k_keys, dim3(blocks_for(nt)), dim3(BT), 0, stream, boxes, live, nt, g, keys_a, vals_a);
+    BCK(hipGetLastError());
+    BCK(hipMemcpyAsync(&h, g, sizeof h, hipMemcpyDeviceToHost, stream));
+    BCK(hipStreamSynchronize(stream));
+    const uint32_t n = h.n_live;
+    if (n > nt) {
+        if (err) *err = "device build: live-triangle count out of range";
+        return hipErrorUnknown;
+    }
+    __builtin_memcpy(&out->maxabs, &h.maxabs, 4);
+    out->n_live = n;
+    if (n == 0) return hipSuccess;
+
+    // (key, triangle) sorted by key; dead triangles (KEY_DEAD) end up behind the n live ones
+    size_t sort_bytes = 0;
+    BCK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)nt, 0, 64, stream));
+    uint8_t* sort_tmp = nullptr;
+    BCK(tmp.get(&sort_tmp, sort_bytes));
+    BCK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)nt, 0, 64, stream));
+    const uint64_t* keys = keys_b;
+    const uint32_t* vals = vals_b;
+
+    TriRec* tris = nullptr;
+    BCK(tmp.get(&tris, n));
+    hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(BT), 0, stream, raw, matidx, vals, n, d_mats, mat_base, n_mats_obj, tris);
+    BCK(hipGetLastError());
+
+    if (n <= lbvh::MAX_LEAF) {   // the whole object is one leaf
+        BCK(hipStreamSynchronize(stream));
+        out->root_ref = make_leaf_ref(slot_base, n);
+        out->tris = tris;
+        tmp.keep(tris);
+        return hipSuccess;
+    }
+
+    lbvh::Tree tree{};
+    uint32_t* arrived = nullptr;
+    BCK(tmp.get(&tree.child_l, n - 1));
+    BCK(tmp.get(&tree.child_r, n - 1));
+    BCK(tmp.get(&tree.first, n - 1));
+    BCK(tmp.get(&tree.last, n - 1));
+    BCK(tmp.get(&tree.parent_inner, n - 1));
+    BCK(tmp.get(&tree.parent_leaf, n));
+    BCK(tmp.get(&tree.ibox, n - 1));
+    BCK(tmp.get(&arrived, n - 1));
+    tree.boxes = boxes;
+    tree.val = vals;
+    BCK(hipMemsetAsync(arrived, 0, (size_t)(n - 1) * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_hier, dim3(blocks_for(n - 1)), dim3(BT), 0, stream, keys, n, tree, g);
+    BCK(hipGetLastError());
+    hipLaunchKernelGGL(k_fit, dim3(blocks_for(n)), dim3(BT), 0, stream, n, tree, arrived);
+    BCK(hipGetLastError());
+    BCK(hipMemcpyAsync(&h, g, sizeof h, hipMemcpyDeviceToHost, stream));
+    BCK(hipStreamSynchronize(stream));
+    const uint32_t n_big = h.n_big;   // the root is one of them (n > MAX_LEAF)
+    if (n_big == 0 || n_big > n - 1) {
+        if (err) *err = "device build: inner-node count out of range";
+        return hipErrorUnknown;
+    }
+
+    Node4* nodes = nullptr;
+    uint2* q[2] = {nullptr, nullptr};
+    BCK(tmp.get(&nodes, n_big));
+    BCK(tmp.get(&q[0], n_big));
+    BCK(tmp.get(&q[1], n_big));
+    // level 1: the root of the binary tree becomes 4-wide node 0
+    const uint2 root_item = make_uint2(0u, 0u);
+    BCK(hipMemcpyAsync(q[0], &root_item, sizeof root_item, hipMemcpyHostToDevice, stream));
+    h.n_nodes = 1;
+    h.q_count[0] = 1;
+    h.q_count[1] = 0;
+    BCK(hipMemcpyAsync(g, &h, sizeof h, hipMemcpyHostToDevice, stream));
+    uint32_t n_in = 1, depth = 0;
+    int cur = 0;
+    while (n_in > 0) {
+        ++depth;
+        if (depth > 4096) {
+            if (err) *err = "device build: collapse did not terminate";
+            return hipErrorUnknown;
+        }
+        hipLaunchKernelGGL(k_collapse, dim3(blocks_for(n_in)), dim3(BT), 0, stream, q[cur], n_in, q[cur ^ 1], n_big, (uint32_t)(cur ^ 1),
+                           tree, nodes, n_big, node_base, slot_base, g);
+        BCK(hipGetLastError());
+        BCK(hipMemcpyAsync(&h, g, sizeof h, hipMemcpyDeviceToHost, stream));
+        BCK(hipStreamSynchronize(stream));
+        if (h.n_nodes > n_big || h.q_count[cur ^ 1] > n_big) {
+            if (err) *err = "device build: node queue overflow";
+            return hipErrorUnknown;
+        }
+        n_in = h.q_count[cur ^ 1];
+        h.q_count[cur] = 0;   // this level's input queue is the next level's output queue
+        BCK(hipMemcpyAsync(&g->q_count[cur], &h.q_count[cur], sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        cur ^= 1;
+    }
+    out->n_nodes = h.n_nodes;
+    out->depth = depth;
+    out->root_ref = node_base;   // 4-wide node 0 of this object
+    out->nodes = nodes;
+    out->tris = tris;
+    tmp.keep(nodes);
+    tmp.keep(tris);
+    return hipSuccess;
+}
+
+}   // namespace trr

@@ -1,0 +1,160 @@
+// lbvh_core.h -- per-element bodies of the device BVH build (build_device.hip), written as plain host/device
+// functions so that tests/test_lbvh_core.py can run the same code serially on the CPU.
+//
+// Stands in, like bvh.cpp, for bvh::Bvh::build (reference call site: src/scene/object.rs:156); the tree's shape is free
+// (bvh.h, "candidate-set invariant").  Algorithm: 63-bit Morton keys of the box centroids, radix sort, the radix-tree
+// construction of Karras 2012 ("Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees": every
+// inner node finds its key range and split independently), bottom-up box fit, then a top-down collapse of the binary
+// tree into the 128-byte 4-wide nodes of bvh.h with <= 4 triangles per leaf.
+#pragma once
+#include <cstdint>
+
+#include "bvh.h"
+
+#ifndef TRR_HD
+#define TRR_HD
+#endif
+
+namespace trr {
+namespace lbvh {
+
+constexpr uint32_t LEAF_BIT = 0x80000000u;   // in child references of the BINARY tree: low bits = sorted position
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint64_t KEY_DEAD = ~0ull;         // key of a triangle left out of the tree (sorts last; live keys use 63 bits)
+constexpr uint32_t MAX_LEAF = 4;
+
+// spreads the low 21 bits of v to every third bit
+TRR_HD inline uint64_t spread3(uint32_t v) {
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+// c: centroid, lo/ext: bounds of all live centroids.  21 bits per axis.
+TRR_HD inline uint64_t morton63(const float c[3], const float lo[3], const float ext[3]) {
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        float f = ext[k] > 0.0f ? (c[k] - lo[k]) / ext[k] : 0.0f;
+        f = f * 2097152.0f;
+        q[k] = !(f > 0.0f) ? 0u : (f >= 2097151.0f ? 2097151u : (uint32_t)f);
+    }
+    return (spread3(q[0]) << 2) | (spread3(q[1]) << 1) | spread3(q[2]);
+}
+
+// length of the common prefix of keys i and j (ties broken by the positions, so equal keys still form a tree)
+TRR_HD inline int common_prefix(const uint64_t* keys, int64_t n, int64_t i, int64_t j) {
+    if (j < 0 || j >= n) return -1;
+    uint64_t a = keys[i], b = keys[j];
+    if (a != b) return __builtin_clzll(a ^ b);
+    return 64 + __builtin_clz((uint32_t)i ^ (uint32_t)j);
+}
+
+struct Tree {                 // the binary radix tree over n sorted leaves (n >= 2): inner nodes 0..n-2, root = 0
+    uint32_t* child_l;        // [n-1]  reference: LEAF_BIT | position, or inner index
+    uint32_t* child_r;        // [n-1]
+    uint32_t* first;          // [n-1]  key range covered by the inner node
+    uint32_t* last;           // [n-1]
+    uint32_t* parent_inner;   // [n-1]  NONE for the root
+    uint32_t* parent_leaf;    // [n]
+    Box3* ibox;               // [n-1]  boxes of the inner nodes (fit pass)
+    const Box3* boxes;        // per-triangle boxes (input order)
+    const uint32_t* val;      // sorted position -> triangle (input order)
+};
+
+// Karras 2012, section 4 ("determine range", "find split") for inner node i.
+TRR_HD inline void build_inner(const uint64_t* keys, int64_t n, int64_t i, const Tree& t) {
+    const int d = (common_prefix(keys, n, i, i + 1) - common_prefix(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = common_prefix(keys, n, i, i - d);
+    int64_t lmax = 2;
+    while (common_prefix(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int64_t l = 0;
+    for (int64_t s = lmax / 2; s >= 1; s /= 2)
+        if (common_prefix(keys, n, i, i + (l + s) * d) > dmin) l += s;
+    const int64_t j = i + l * d;
+    const int dnode = common_prefix(keys, n, i, j);
+    int64_t s = 0, step = l;
+    do {
+        step = (step + 1) >> 1;
+        if (common_prefix(keys, n, i, i + (s + step) * d) > dnode) s += step;
+    } while (step > 1);
+    const int64_t gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
+    const uint32_t cl = (lo == gamma) ? (LEAF_BIT | (uint32_t)gamma) : (uint32_t)gamma;
+    const uint32_t cr = (hi == gamma + 1) ? (LEAF_BIT | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+    t.child_l[i] = cl;
+    t.child_r[i] = cr;
+    t.first[i] = (uint32_t)lo;
+    t.last[i] = (uint32_t)hi;
+    if (cl & LEAF_BIT) t.parent_leaf[gamma] = (uint32_t)i; else t.parent_inner[gamma] = (uint32_t)i;
+    if (cr & LEAF_BIT) t.parent_leaf[gamma + 1] = (uint32_t)i; else t.parent_inner[gamma + 1] = (uint32_t)i;
+    if (i == 0) t.parent_inner[0] = NONE;
+}
+
+TRR_HD inline float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+TRR_HD inline float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+TRR_HD inline Box3 box_union(const Box3& a, const Box3& b) {
+    Box3 r;
+    for (int k = 0; k < 3; ++k) { r.lo[k] = fmin_(a.lo[k], b.lo[k]); r.hi[k] = fmax_(a.hi[k], b.hi[k]); }
+    return r;
+}
+TRR_HD inline float box_half_area(const Box3& b) {   // bvh.cpp half_area
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    if (!(dx >= 0.0f) || !(dy >= 0.0f) || !(dz >= 0.0f)) return 0.0f;
+    float a = dx * dy + dy * dz + dz * dx;
+    return (a - a == 0.0f) ? a : 3.402823466e+38f;
+}
+
+// a child of the binary tree that becomes a LEAF of the 4-wide tree: a single triangle or a subtree of <= 4
+TRR_HD inline bool leaf_like(const Tree& t, uint32_t ref) {
+    return (ref & LEAF_BIT) || (t.last[ref] - t.first[ref] + 1u <= MAX_LEAF);
+}
+TRR_HD inline Box3 ref_box(const Tree& t, uint32_t ref) {
+    return (ref & LEAF_BIT) ? t.boxes[t.val[ref & ~LEAF_BIT]] : t.ibox[ref];
+}
+
+// Children of the 4-wide node rooted at binary inner node b: its two children, then repeatedly the child with the
+// largest box that is not leaf-like is replaced by its own two children (same rule as bvh.cpp's Collapser).
+// Returns the number of children (2..4) and fills kids[] with binary-tree references.
+TRR_HD inline int collapse_children(const Tree& t, uint32_t b, uint32_t kids[4]) {
+    int nk = 2;
+    kids[0] = t.child_l[b];
+    kids[1] = t.child_r[b];
+    while (nk < 4) {
+        int pick = -1;
+        float pa = -1.0f;
+        for (int k = 0; k < nk; ++k) {
+            if (leaf_like(t, kids[k])) continue;
+            float a = box_half_area(t.ibox[kids[k]]);
+            if (a > pa) { pa = a; pick = k; }
+        }
+        if (pick < 0) break;
+        uint32_t p = kids[pick];
+        kids[pick] = t.child_l[p];
+        kids[nk++] = t.child_r[p];
+    }
+    return nk;
+}
+
+// Leaf reference of the 4-wide tree for a leaf-like child (slots are sorted positions + slot_base).
+TRR_HD inline uint32_t leaf_ref_of(const Tree& t, uint32_t ref, uint32_t slot_base) {
+    if (ref & LEAF_BIT) return REF_LEAF | (((ref & ~LEAF_BIT) + slot_base) << 2);
+    return REF_LEAF | ((t.first[ref] + slot_base) << 2) | (t.last[ref] - t.first[ref]);
+}
+
+TRR_HD inline void node4_set_box(Node4& nd, int k, const Box3& bx) {
+    nd.lox[k] = bx.lo[0]; nd.loy[k] = bx.lo[1]; nd.loz[k] = bx.lo[2];
+    nd.hix[k] = bx.hi[0]; nd.hiy[k] = bx.hi[1]; nd.hiz[k] = bx.hi[2];
+}
+TRR_HD inline void node4_set_empty(Node4& nd, int k) {   // never hit: see bvh.cpp
+    const float inf = __builtin_inff();
+    nd.lox[k] = nd.loy[k] = nd.loz[k] = inf;
+    nd.hix[k] = nd.hiy[k] = nd.hiz[k] = inf;
+    nd.child[k] = REF_EMPTY;
+}
+
+}   // namespace lbvh
+}   // namespace trr

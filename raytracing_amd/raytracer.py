@@ -97,7 +97,12 @@ class Raytracer:
     (the reference deep-clones it, render.rs:60) and renders it with the gfx950 kernels."""
 
     def __init__(self, scene: Scene, delta: float = DEFAULT_DELTA, max_depth: int = DEFAULT_MAX_DEPTH,
-                 context: Optional[Context] = None, device: int = 0):
+                 context: Optional[Context] = None, device: int = 0, build: str = "host"):
+        """``build``: "host" = binned-SAH BVH on the host cores (best tree), "device" = LBVH on the GPU (fastest
+        upload; for scenes that change between renders).  Same image either way (include/trayracer_hip.h)."""
+        if build not in ("host", "device"):
+            raise ValueError("build must be 'host' or 'device'")
+        self.build = build
         self.ctx = context or Context(device)
         self.delta = float(delta)
         self.max_depth = int(max_depth)
@@ -149,13 +154,24 @@ class Raytracer:
             imgs[k].rgb = t.ctypes.data
             imgs[k].height, imgs[k].width = t.shape[0], t.shape[1]
         t0 = time.perf_counter()
-        N.check(L.trr_scene_create(self.ctx.handle, C.addressof(objs), len(scene.objects), C.addressof(imgs),
-                                   len(textures), C.byref(self._scene)), self.ctx.handle)
+        N.check(L.trr_scene_create_ex(self.ctx.handle, C.addressof(objs), len(scene.objects), C.addressof(imgs), len(textures),
+                                      N.TRR_BUILD_DEVICE if self.build == "device" else N.TRR_BUILD_HOST,
+                                      C.byref(self._scene)), self.ctx.handle)
         self.upload_seconds = time.perf_counter() - t0
         del keep
         self.set_lights(scene.lights)
         self.set_settings(scene.settings)
         self.set_camera(scene.camera)
+
+    def scene_info(self) -> dict:
+        """Triangle / node counts, tree depth and build time of the uploaded scene (trr_scene_get_info)."""
+        info = N.SceneInfo()
+        N.check(N.lib().trr_scene_get_info(self._scene, C.addressof(info)), self.ctx.handle)
+        return info.as_dict()
+
+    def validate(self) -> None:
+        """Checks the uploaded BVH on the host (trr_scene_validate); raises NativeError with the first violation."""
+        N.check(N.lib().trr_scene_validate(self._scene), self.ctx.handle)
 
     def set_lights(self, lights):
         arr = (N.LightDesc * max(1, len(lights)))()

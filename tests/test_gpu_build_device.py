@@ -1,0 +1,117 @@
+"""GPU tests of the device BVH build (TRR_BUILD_DEVICE of include/trayracer_hip.h).
+
+The reference builds each object's Bvh on the CPU (object.rs:156); its closest hit is a min over every triangle whose
+own box the ray passes (object.rs:191-206), so the image does not depend on the tree.  The tests therefore demand that
+a scene uploaded with the GPU builder renders BYTE-IDENTICAL pixels and ids to the same scene uploaded with the host
+builder (which the parity tests pin against the oracle), that it matches the oracle directly, and that the tree passes
+trr_scene_validate (every live triangle in one leaf, boxes nested, references in range).
+"""
+import numpy as np
+import pytest
+
+from raytracing_amd import _native as N
+from raytracing_amd import standin
+from raytracing_amd.raytracer import Raytracer
+from raytracing_amd.scene import Light, Object, Scene, Settings
+from tests._util import assert_parity
+from tests.test_oracle_kat import front_camera, mat, tri_rows
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from raytracing_amd.raytracer import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def render_both(ctx, scene, max_depth=5, **kw):
+    out = {}
+    for build in ("host", "device"):
+        rt = Raytracer(scene, max_depth=max_depth, context=ctx, build=build)
+        try:
+            rt.validate()
+            out[build] = (rt.render_frame(want_ids=True, **kw), rt.scene_info())
+        finally:
+            rt.close()
+    return out
+
+
+def assert_same(out, what):
+    (h, hi), (d, di) = out["host"], out["device"]
+    assert hi["build"] == N.TRR_BUILD_HOST and di["build"] == N.TRR_BUILD_DEVICE
+    assert hi["n_triangles"] == di["n_triangles"] and hi["n_triangles_live"] == di["n_triangles_live"], what
+    assert np.array_equal(h["hit_obj"], d["hit_obj"]), what + ": object ids differ between the builders"
+    assert np.array_equal(h["hit_tri"], d["hit_tri"]), what + ": triangle ids differ between the builders"
+    assert np.array_equal(h["rgb"], d["rgb"]), what + ": pixels differ between the builders"
+
+
+@pytest.mark.parametrize("sky_image", [True, False])
+def test_parity_scene_is_identical_with_both_builders(ctx, oracle_mod, sky_image):
+    sc = standin.parity_scene(200, 150, detail=14, sky_image=sky_image)
+    out = render_both(ctx, sc, max_depth=5)
+    assert_same(out, "parity scene")
+    ref = oracle_mod.OracleScene(sc).render(shade=oracle_mod.SHADE_HOISTED, max_depth=5)
+    assert_parity(out["device"][0], ref, what="device-built parity scene against the oracle")
+
+
+def test_standin_scenes_are_identical_with_both_builders(ctx):
+    for name, sc, md in [("test scene", standin.standin_test(400, 300, n_car=120_000, n_floor=30_000), 2),
+                         ("mirrors", standin.standin_mirrors(240, 160, n_spheres=9, tris_per_sphere=600, sky=(256, 128)), 9),
+                         ("terrain", standin.standin_terrain(240, 160, nx=200, nz=100), 5)]:
+        out = render_both(ctx, sc, max_depth=md)
+        assert_same(out, name)
+        info = out["device"][1]
+        assert info["n_nodes"] > 0 and 1 <= info["bvh_depth"] < 64, info
+
+
+def test_small_dead_and_duplicate_triangles(ctx, oracle_mod):
+    """Root-leaf objects (1..4 triangles), an empty object, triangles the reference can never hit (left out of the tree),
+    NaN vertices, and many identical triangles (equal Morton keys: the radix tree falls back to the positions)."""
+    z = -3.0
+    one = tri_rows(((-1, -1, z), (1, -1, z), (0, 1, z)))
+    three = tri_rows(((-2, -1, z - 1), (0, -1, z - 1), (-1, 1, z - 1)), ((0, -1, z - 1), (2, -1, z - 1), (1, 1, z - 1)),
+                     ((-1, 1, z - 1), (1, 1, z - 1), (0, 2, z - 1)))
+    dup = np.repeat(tri_rows(((-0.5, -0.5, z + 1), (0.5, -0.5, z + 1), (0, 0.5, z + 1))), 37, axis=0)
+    rows = [((-1, -1, z - 2), (1, -1, z - 2), (1, 1, z - 2)),
+            ((0, 0, z), (0, 0, z), (0, 0, z)),                               # zero area: never in the tree
+            ((float("nan"), 0, z), (1, 0, z), (0, 1, z)),                    # NaN vertex
+            ((-1, -1, z - 2), (1, 1, z - 2), (-1, 1, z - 2))]
+    for k in range(9):                                                       # a strip of thin triangles on a line
+        x = -1.0 + 0.2 * k
+        rows.append(((x, -1.5, z - 0.5), (x + 0.2, -1.5, z - 0.5), (x + 0.1, -1.2, z - 0.5)))
+    mixed = tri_rows(*rows)
+    m = [mat(kd=(0.4, 0.5, 0.6), illum=2, ks=(1, 1, 1), ns=5.0, dissolve=0.0)]
+    objs = [Object(triangles=one, material_index=np.array([-1], np.int32)), Object(),
+            Object(triangles=three, material_index=np.zeros(3, np.int32), materials=m),
+            Object(triangles=dup, material_index=np.zeros(len(dup), np.int32), materials=m),
+            Object(triangles=mixed, material_index=np.zeros(len(mixed), np.int32), materials=m)]
+    sc = Scene(objects=objs, lights=[Light(np.array([0.5, 2.0, 0], F32), np.array([1, 1, 1], F32), 9.0)],
+               camera=front_camera(96, 72), settings=Settings())
+    out = render_both(ctx, sc)
+    assert_same(out, "small / dead / duplicate triangles")
+    assert out["device"][1]["n_triangles_live"] == out["device"][1]["n_triangles"] - 1
+    ref = oracle_mod.OracleScene(sc).render()
+    assert_parity(out["device"][0], ref, what="device build, edge cases")
+    assert sorted(set(np.unique(out["device"][0]["hit_obj"]).tolist()) - {0xFFFFFFFF}) == [0, 2, 3, 4]
+
+
+def test_million_triangle_build_validates_and_renders_the_same(ctx):
+    """The benchmark's mesh (BASELINE.json configs[1], 1.03 M triangles): device-built tree checked on the host, and a
+    quarter-size frame identical to the host-built one."""
+    sc = standin.standin_car(960, 540, n_tris=1_027_464)
+    out = render_both(ctx, sc, max_depth=5)
+    assert_same(out, "standin_car 1 M")
+    hi, di = out["host"][1], out["device"][1]
+    print(f"\nbuild ms: host {hi['ms_build']:.1f} (depth {hi['bvh_depth']}, {hi['n_nodes']} nodes)  "
+          f"device {di['ms_build']:.1f} (depth {di['bvh_depth']}, {di['n_nodes']} nodes)")
+
+
+def test_unknown_build_mode_is_rejected(ctx):
+    import ctypes as C
+    h = C.c_void_p()
+    rc = N.lib().trr_scene_create_ex(ctx.handle, None, 0, None, 0, 7, C.byref(h))
+    assert rc == N.TRR_ERR_INVALID and not h
