@@ -54,6 +54,8 @@ def main():
                     help="buffer sets / render streams alternated by consecutive frames (1 = each frame waits for the previous one)")
     ap.add_argument("--no-launch-events", action="store_true",
                     help="experiment: time the frames without per-launch HIP events (the roofline object is then null)")
+    ap.add_argument("--build", choices=("host", "device"), default="host",
+                    help="where the BVH is built (outside the timed region): host SAH (default, best tree) or GPU LBVH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "16")))
     args = ap.parse_args()
@@ -87,7 +89,7 @@ def main():
     aa = args.spp > 1
     scene = standin.standin_car(args.width, args.height, n_tris=args.tris, seed=1, anti_aliasing=aa, samples=max(1, args.spp))
     t0 = time.perf_counter()
-    rt = Raytracer(scene, max_depth=args.max_depth, device=local_rank)
+    rt = Raytracer(scene, max_depth=args.max_depth, device=local_rank, build=args.build)
     upload_s = time.perf_counter() - t0
     sr = ShardedRenderer(rt, rank, world, use_dist=distributed, frames_in_flight=args.frames_in_flight)
 
@@ -207,7 +209,7 @@ def main():
             "config": {"workload": f"car_objs stand-in (procedural, {scene.triangle_count()} triangles, one object) "
                                    f"{args.width}x{args.height}, {args.spp} spp, max_depth {args.max_depth} "
                                    f"(reflection depth {args.max_depth - 1}), 4 lights, tiles sharded over {world} GPU(s)",
-                       "rays_per_frame": frame_rays, "scene_upload_s": round(upload_s, 2),
+                       "rays_per_frame": frame_rays, "scene_upload_s": round(upload_s, 2), "bvh_build": args.build,
                        "frames_in_flight": args.frames_in_flight},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -4,7 +4,7 @@
 //   Scene::load (include/trayracer_loader.hpp) -> Raytracer(scene, 1e-5, 5) (render.rs:105) -> RGB8 frame -> file.
 //
 //   usage: trr_cli <scene.yaml> [-o out.png|out.ppm] [--width W] [--height H] [--max-depth D] [--delta E]
-//                  [--anti-aliasing on|off] [--samples N] [--seed S] [--device K] [--dump-scene file] [--no-render] [--stats]
+//                  [--anti-aliasing on|off] [--samples N] [--seed S] [--device K] [--build host|device] [--dump-scene file] [--no-render] [--stats]
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
     int aa = -1;
     long long seed = -1;
     bool no_render = false, stats = false;
+    Build build = Build::Host;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto val = [&]() -> std::string {
@@ -71,6 +72,11 @@ int main(int argc, char** argv) {
         else if (a == "--samples") samples = std::atol(val().c_str());
         else if (a == "--seed") seed = std::atoll(val().c_str());
         else if (a == "--device") device = std::atoi(val().c_str());
+        else if (a == "--build") {
+            std::string b = val();
+            if (b != "host" && b != "device") { std::fprintf(stderr, "error: --build takes host or device\n"); return 2; }
+            build = b == "device" ? Build::Device : Build::Host;
+        }
         else if (a == "--dump-scene") dump = val();
         else if (a == "--no-render") no_render = true;
         else if (a == "--stats") stats = true;
@@ -79,7 +85,7 @@ int main(int argc, char** argv) {
     }
     if (scene_path.empty()) {
         std::fprintf(stderr, "usage: %s <scene.yaml> [-o out.png|out.ppm] [--width W] [--height H] [--max-depth D] [--anti-aliasing on|off] "
-                             "[--samples N] [--seed S] [--device K] [--dump-scene file] [--no-render] [--stats]\n", argv[0]);
+                             "[--samples N] [--seed S] [--device K] [--build host|device] [--dump-scene file] [--no-render] [--stats]\n", argv[0]);
         return 2;
     }
     Scene sc;
@@ -98,7 +104,7 @@ int main(int argc, char** argv) {
     if (no_render) return 0;
     try {
         auto ctx = std::make_shared<Context>(device);   // throws when no HIP device exists: there is no CPU fallback
-        Raytracer rt(ctx, sc, delta, max_depth);
+        Raytracer rt(ctx, sc, delta, max_depth, build);
         Image im;
         im.width = rt.width(); im.height = rt.height();
         im.rgb.assign((size_t)im.width * im.height * 3, 0);
@@ -113,8 +119,11 @@ int main(int argc, char** argv) {
             unsigned long long rays = st.rays_primary + st.rays_shadow + st.rays_reflection + st.rays_march;
             size_t tris = 0;
             for (auto& o : sc.objects) tris += o.triangles.size();
-            std::printf("{\"scene\": \"%s\", \"triangles\": %zu, \"resolution\": [%u, %u], \"rays\": %llu, \"ms_render\": %.3f, \"output\": \"%s\"}\n",
-                        scene_path.c_str(), tris, im.width, im.height, rays, st.ms_total, out.c_str());
+            trr_scene_info info = rt.info();
+            std::printf("{\"scene\": \"%s\", \"triangles\": %zu, \"resolution\": [%u, %u], \"rays\": %llu, \"ms_render\": %.3f, "
+                        "\"build\": \"%s\", \"ms_build\": %.3f, \"bvh_nodes\": %llu, \"bvh_depth\": %u, \"output\": \"%s\"}\n",
+                        scene_path.c_str(), tris, im.width, im.height, rays, st.ms_total, info.build == TRR_BUILD_DEVICE ? "device" : "host",
+                        info.ms_build, (unsigned long long)info.n_nodes, info.bvh_depth, out.c_str());
         }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());

@@ -193,10 +193,14 @@ private:
 
 // Raytracer::new(scene, delta, max_depth) (raytracer/mod.rs:37): uploads a flattened copy of the scene (the reference
 // deep-clones it, render.rs:60) and renders it with the gfx950 kernels.  One render at a time per Context.
+// Where the BVH that stands in for bvh::Bvh::build (object.rs:156) is built: Host = binned SAH on the CPU cores (best
+// tree), Device = LBVH on the GPU (an order of magnitude faster to build; for scenes edited between renders).
+enum class Build : uint32_t { Host = TRR_BUILD_HOST, Device = TRR_BUILD_DEVICE };
+
 class Raytracer {
 public:
-    Raytracer(std::shared_ptr<Context> ctx, const Scene& scene, float delta = 1e-5f, uint32_t max_depth = 5)
-        : ctx_(std::move(ctx)), delta_(delta), max_depth_(max_depth) {
+    Raytracer(std::shared_ptr<Context> ctx, const Scene& scene, float delta = 1e-5f, uint32_t max_depth = 5, Build build = Build::Host)
+        : ctx_(std::move(ctx)), delta_(delta), max_depth_(max_depth), build_(build) {
         upload(scene);
     }
     ~Raytracer() { trr_scene_destroy(scene_); }
@@ -205,6 +209,13 @@ public:
 
     uint32_t width() const { return width_; }
     uint32_t height() const { return height_; }
+    trr_scene_info info() const {
+        trr_scene_info i{};
+        ctx_->check(trr_scene_get_info(scene_, &i));
+        return i;
+    }
+    // host-side check of the uploaded tree (trr_scene_validate); throws Error with the first violation
+    void validate() { ctx_->check(trr_scene_validate(scene_)); }
 
     // ui/properties.rs edits between renders: lights, settings, camera (cheap, no BVH rebuild)
     void set_lights(const std::vector<Light>& lights) {
@@ -307,7 +318,8 @@ private:
             od.n_materials = (uint32_t)o.materials.size();
             o.transform(od.transform, od.inverse);
         }
-        ctx_->check(trr_scene_create(ctx_->get(), objs.data(), (uint32_t)objs.size(), textures.data(), (uint32_t)textures.size(), &scene_));
+        ctx_->check(trr_scene_create_ex(ctx_->get(), objs.data(), (uint32_t)objs.size(), textures.data(), (uint32_t)textures.size(),
+                                        (uint32_t)build_, &scene_));
         set_lights(scene.lights);
         set_settings(scene.settings);
         set_camera(scene.camera);
@@ -317,6 +329,7 @@ private:
     trr_scene* scene_ = nullptr;
     float delta_;
     uint32_t max_depth_;
+    Build build_ = Build::Host;
     uint32_t width_ = 0, height_ = 0;
 };
 

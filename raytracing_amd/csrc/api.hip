@@ -403,6 +403,7 @@ static int build_scene_device(trr_ctx* ctx, trr_scene* sc, const trr_object_desc
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     free_parts();
+    if (std::getenv("TRR_DEBUG")) std::fprintf(stderr, "[trr build] packed %llu nodes, %llu triangles\n", (unsigned long long)node_base, (unsigned long long)slot_base);
     if (e != hipSuccess) return fail(ctx, TRR_ERR_DEVICE, std::string("device BVH build: packing the objects: ") + hipGetErrorString(e));
     sc->n_nodes = node_base;
     sc->n_tris_live = slot_base;

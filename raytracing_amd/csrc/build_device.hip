@@ -7,12 +7,16 @@
 // trr_scene_validate and by the parity tests, which render the same scene with both builders.
 //
 // Pipeline (all HBM-bound, one pass each over n triangles): prep (raw 96-B triangles -> box, InterpRec, live flag,
-// centroid bounds) -> 63-bit Morton keys -> hipCUB radix sort of (key, triangle) -> Karras radix tree -> bottom-up box
-// fit -> level-by-level collapse into 128-B 4-wide nodes -> gather of the 64-B TriRecs into leaf order.
+// centroid bounds) -> 63-bit Morton keys -> hipCUB radix sort of (key, triangle) -> gather of the 64-B TriRecs and the
+// boxes into leaf order -> Karras radix tree -> box fit by range unions over a pairwise-union pyramid (no atomics, no
+// fences: lbvh_core.h) -> level-by-level collapse into 128-B 4-wide nodes.
 #include "build_device.h"
 
 #include <hipcub/hipcub.hpp>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define TRR_HD __host__ __device__
@@ -46,10 +50,6 @@ struct Globals {            // one small device record per build, zero-initialis
     uint32_t q_count[2];    // items in the two collapse queues
 };
 
-struct Tri9 {
-    float a[3], b[3], c[3];
-};
-
 __device__ inline void load_raw(const float* raw, uint32_t t, float f[24]) {
     const float4* p = reinterpret_cast<const float4*>(raw + (size_t)t * 24);   // 96-B rows of a hipMalloc'd array
 #pragma unroll
@@ -78,20 +78,22 @@ __device__ inline float wave_max(float v) {
     return v;
 }
 
+// Grid-stride over the triangles with a bounded grid: the eight reductions end in same-address atomics (one set per
+// wavefront), which serialise -- one set per 64 triangles cost 14 ms for 10 M triangles, one set per resident wavefront
+// costs nothing.
 __global__ void __launch_bounds__(BT) k_prep(const float* __restrict__ raw, uint32_t nt, InterpRec* __restrict__ interp,
                                              Box3* __restrict__ boxes, uint8_t* __restrict__ live, Globals* g) {
-    const uint32_t t = blockIdx.x * BT + threadIdx.x;
-    const bool valid = t < nt;
     const float inf = __builtin_inff();
     float cmin[3] = {inf, inf, inf}, cmax[3] = {-inf, -inf, -inf};
     float ma = 0.0f;
-    bool is_live = false;
-    if (valid) {
+    uint32_t n_live = 0;
+    for (uint64_t t64 = (uint64_t)blockIdx.x * BT + threadIdx.x; t64 < nt; t64 += (uint64_t)gridDim.x * BT) {
+        const uint32_t t = (uint32_t)t64;
         float f[24];
         load_raw(raw, t, f);
         float n[3], len;
         normal_of(f, n, &len);
-        is_live = !(len <= 0.0f);   // |ab x ac| == 0 can never be hit for any delta >= 0 (triangle.rs:56)
+        const bool is_live = !(len <= 0.0f);   // |ab x ac| == 0 can never be hit for any delta >= 0 (triangle.rs:56)
         // triangle.rs:88-95: Aabb::empty().grow(a).grow(b).grow(c + 1e-4)
         Box3 bx;
 #pragma unroll
@@ -108,11 +110,13 @@ __global__ void __launch_bounds__(BT) k_prep(const float* __restrict__ raw, uint
             if ((v - v == 0.0f) && v > ma) ma = v;
         }
         if (is_live) {
+            ++n_live;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 float c = 0.5f * bx.lo[k] + 0.5f * bx.hi[k];
                 if (!(c - c == 0.0f)) c = 0.0f;   // NaN / infinite vertices must not poison the keys
-                cmin[k] = c; cmax[k] = c;
+                cmin[k] = fminf(cmin[k], c);
+                cmax[k] = fmaxf(cmax[k], c);
             }
         }
         float4* ip = reinterpret_cast<float4*>(interp + t);
@@ -122,22 +126,23 @@ __global__ void __launch_bounds__(BT) k_prep(const float* __restrict__ raw, uint
         ip[3] = make_float4(f[21], f[22], f[23], 0.0f);     // uvb.y, uvc, pad
     }
     // every lane of the wavefront takes part in the reductions
-    const unsigned long long lm = __ballot(is_live);
 #pragma unroll
     for (int k = 0; k < 3; ++k) { cmin[k] = wave_min(cmin[k]); cmax[k] = wave_max(cmax[k]); }
     ma = wave_max(ma);
+    for (int o = 32; o >= 1; o >>= 1) n_live += __shfl_xor(n_live, o, 64);
     if ((threadIdx.x & 63) == 0) {
-        if (lm) {
+        if (n_live) {
             for (int k = 0; k < 3; ++k) {
                 atomicMin(&g->cmin[k], f2ord(cmin[k]));
                 atomicMax(&g->cmax[k], f2ord(cmax[k]));
             }
-            atomicAdd(&g->n_live, (uint32_t)__popcll(lm));
+            atomicAdd(&g->n_live, n_live);
         }
         if (ma > 0.0f) atomicMax(&g->maxabs, __float_as_uint(ma));
     }
 }
 
+template <bool UNIFORM_PER_AXIS>
 __global__ void __launch_bounds__(BT) k_keys(const Box3* __restrict__ boxes, const uint8_t* __restrict__ live, uint32_t nt,
                                              const Globals* g, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t t = blockIdx.x * BT + threadIdx.x;
@@ -152,6 +157,9 @@ __global__ void __launch_bounds__(BT) k_keys(const Box3* __restrict__ boxes, con
             c[k] = 0.5f * bx.lo[k] + 0.5f * bx.hi[k];
             if (!(c[k] - c[k] == 0.0f)) c[k] = 0.0f;
         }
+        // one scale for the three axes (cubic Morton cells): a flat object (a terrain) is then not split along its thin
+        // axis as often as along the others (measured: 10 M-triangle heightfield frame 5.2 -> see DESIGN.md)
+        if (!UNIFORM_PER_AXIS) ext[0] = ext[1] = ext[2] = fmaxf(fmaxf(ext[0], ext[1]), ext[2]);
         key = lbvh::morton63(c, lo, ext);
     }
     keys[t] = key;
@@ -159,47 +167,31 @@ __global__ void __launch_bounds__(BT) k_keys(const Box3* __restrict__ boxes, con
 }
 
 __global__ void __launch_bounds__(BT) k_hier(const uint64_t* __restrict__ keys, uint32_t n, lbvh::Tree tree, Globals* g) {
+    __shared__ uint32_t s_big;
+    if (threadIdx.x == 0) s_big = 0;
+    __syncthreads();
     const uint32_t i = blockIdx.x * BT + threadIdx.x;
     bool big = false;
     if (i + 1 < n) {
         lbvh::build_inner(keys, (int64_t)n, (int64_t)i, tree);
-        big = tree.last[i] - tree.first[i] + 1u > lbvh::MAX_LEAF;
+        big = tree.last[i] - tree.first[i] + 1u > tree.max_leaf;
     }
     const unsigned long long m = __ballot(big);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&g->n_big, (uint32_t)__popcll(m));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_big, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_big) atomicAdd(&g->n_big, s_big);   // one same-address atomic per workgroup
 }
 
-__device__ inline Box3 load_box_coherent(const Box3* p) {
-    // written by another workgroup during this launch: read past the (non-coherent) vector L1
-    Box3 r;
-    for (int k = 0; k < 3; ++k) {
-        r.lo[k] = __hip_atomic_load(&p->lo[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.hi[k] = __hip_atomic_load(&p->hi[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return r;
+// next level of the pairwise-union pyramid
+__global__ void __launch_bounds__(BT) k_pyramid(const Box3* __restrict__ src, uint32_t n_src, Box3* __restrict__ dst, uint32_t n_dst) {
+    const uint32_t j = blockIdx.x * BT + threadIdx.x;
+    if (j < n_dst) dst[j] = lbvh::pyramid_pair(src, n_src, j);
 }
 
-// One thread per leaf walks towards the root; at every inner node the first arrival stops, the second one (which
-// therefore sees both children finished) writes the node's box and goes on.  Every thread ends after at most
-// tree-depth steps; nothing waits.
-__global__ void __launch_bounds__(BT) k_fit(uint32_t n, lbvh::Tree tree, uint32_t* __restrict__ arrived) {
-    const uint32_t s = blockIdx.x * BT + threadIdx.x;
-    if (s >= n) return;
-    Box3 box = tree.boxes[tree.val[s]];
-    uint32_t me = lbvh::LEAF_BIT | s;
-    uint32_t p = tree.parent_leaf[s];
-    while (p != lbvh::NONE) {
-        __threadfence();                                   // my box (if any) is visible before the arrival count
-        if (atomicAdd(&arrived[p], 1u) == 0u) return;
-        __threadfence();
-        const uint32_t l = tree.child_l[p], r = tree.child_r[p];
-        const uint32_t sib = (l == me) ? r : l;
-        const Box3 sb = (sib & lbvh::LEAF_BIT) ? tree.boxes[tree.val[sib & ~lbvh::LEAF_BIT]] : load_box_coherent(&tree.ibox[sib]);
-        box = lbvh::box_union(box, sb);
-        tree.ibox[p] = box;
-        me = p;
-        p = tree.parent_inner[p];
-    }
+// box of every inner node = union of the sorted boxes first..last
+__global__ void __launch_bounds__(BT) k_fit(uint32_t n, lbvh::Tree tree, lbvh::Pyramid pyr) {
+    const uint32_t i = blockIdx.x * BT + threadIdx.x;
+    if (i + 1 < n) tree.ibox[i] = lbvh::range_box(pyr, tree.first[i], tree.last[i]);
 }
 
 // One level of the top-down collapse: every queue item (binary inner node, index of its 4-wide node) writes its node
@@ -240,10 +232,12 @@ __global__ void __launch_bounds__(BT) k_collapse(const uint2* __restrict__ q_in,
 
 __global__ void __launch_bounds__(BT) k_gather(const float* __restrict__ raw, const int32_t* __restrict__ matidx,
                                                const uint32_t* __restrict__ vals, uint32_t n_live, const MatRec* __restrict__ mats,
-                                               uint32_t mat_base, uint32_t n_mats_obj, TriRec* __restrict__ out) {
+                                               uint32_t mat_base, uint32_t n_mats_obj, const Box3* __restrict__ boxes,
+                                               TriRec* __restrict__ out, Box3* __restrict__ sorted_boxes) {
     const uint32_t s = blockIdx.x * BT + threadIdx.x;
     if (s >= n_live) return;
     const uint32_t t = vals[s];
+    sorted_boxes[s] = boxes[t];
     float f[24];
     load_raw(raw, t, f);
     float n[3], len;
@@ -296,6 +290,16 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
                                DeviceBuildOut* out, std::string* err) {
     *out = DeviceBuildOut{};
     if (nt == 0) return hipSuccess;
+    // TRR_DEBUG=1: wall-clock marks of the stages (each mark waits for the stream)
+    const bool debug = std::getenv("TRR_DEBUG") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!debug) return;
+        (void)hipStreamSynchronize(stream);
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[trr build] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     Tmp tmp;
     float* raw = nullptr;
     int32_t* matidx = nullptr;
@@ -312,6 +316,7 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
     BCK(tmp.get(&keys_b, nt));
     BCK(tmp.get(&vals_a, nt));
     BCK(tmp.get(&vals_b, nt));
+    mark("allocations");
     BCK(hipMemcpyAsync(raw, h_tris, (size_t)nt * 24 * sizeof(float), hipMemcpyHostToDevice, stream));
     if (h_matidx) {
         BCK(tmp.get(&matidx, nt));
@@ -320,13 +325,18 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
     Globals h{};
     for (int k = 0; k < 3; ++k) { h.cmin[k] = 0xFFFFFFFFu; h.cmax[k] = 0u; }
     BCK(hipMemcpyAsync(g, &h, sizeof h, hipMemcpyHostToDevice, stream));
+    mark("host to device");
 
-    hipLaunchKernelGGL(k_prep, dim3(blocks_for(nt)), dim3(BT), 0, stream, raw, nt, d_interp, boxes, live, g);
+    hipLaunchKernelGGL(k_prep, dim3(std::min(blocks_for(nt), 2048u)), dim3(BT), 0, stream, raw, nt, d_interp, boxes, live, g);
     BCK(hipGetLastError());
-    hipLaunchKernelGGL(k_keys, dim3(blocks_for(nt)), dim3(BT), 0, stream, boxes, live, nt, g, keys_a, vals_a);
+    if (std::getenv("TRR_LBVH_PER_AXIS"))   // experiments: every axis scaled to its own extent
+        hipLaunchKernelGGL(k_keys<true>, dim3(blocks_for(nt)), dim3(BT), 0, stream, boxes, live, nt, g, keys_a, vals_a);
+    else
+        hipLaunchKernelGGL(k_keys<false>, dim3(blocks_for(nt)), dim3(BT), 0, stream, boxes, live, nt, g, keys_a, vals_a);
     BCK(hipGetLastError());
     BCK(hipMemcpyAsync(&h, g, sizeof h, hipMemcpyDeviceToHost, stream));
     BCK(hipStreamSynchronize(stream));
+    mark("prep + keys");
     const uint32_t n = h.n_live;
     if (n > nt) {
         if (err) *err = "device build: live-triangle count out of range";
@@ -344,13 +354,22 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
     BCK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)nt, 0, 64, stream));
     const uint64_t* keys = keys_b;
     const uint32_t* vals = vals_b;
+    mark("sort");
 
     TriRec* tris = nullptr;
+    Box3* pyr_base = nullptr;
+    lbvh::Pyramid pyr{};
+    const uint32_t pyr_total = lbvh::pyramid_layout(n, pyr.off, &pyr.levels);
     BCK(tmp.get(&tris, n));
-    hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(BT), 0, stream, raw, matidx, vals, n, d_mats, mat_base, n_mats_obj, tris);
+    BCK(tmp.get(&pyr_base, pyr_total));
+    pyr.base = pyr_base;
+    hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(BT), 0, stream, raw, matidx, vals, n, d_mats, mat_base, n_mats_obj, boxes, tris,
+                       pyr_base);
     BCK(hipGetLastError());
 
-    if (n <= lbvh::MAX_LEAF) {   // the whole object is one leaf
+    uint32_t max_leaf = 2;   // measured: leaves of <= 2 trace 3-10 % faster than <= 4 (more, smaller boxes; as bvh.cpp's ALWAYS_LEAF)
+    if (const char* e = std::getenv("TRR_LBVH_MAX_LEAF")) max_leaf = (uint32_t)std::min(4, std::max(1, std::atoi(e)));   // experiments
+    if (n <= max_leaf) {   // the whole object is one leaf
         BCK(hipStreamSynchronize(stream));
         out->root_ref = make_leaf_ref(slot_base, n);
         out->tris = tris;
@@ -359,25 +378,30 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
     }
 
     lbvh::Tree tree{};
-    uint32_t* arrived = nullptr;
     BCK(tmp.get(&tree.child_l, n - 1));
     BCK(tmp.get(&tree.child_r, n - 1));
     BCK(tmp.get(&tree.first, n - 1));
     BCK(tmp.get(&tree.last, n - 1));
-    BCK(tmp.get(&tree.parent_inner, n - 1));
-    BCK(tmp.get(&tree.parent_leaf, n));
     BCK(tmp.get(&tree.ibox, n - 1));
-    BCK(tmp.get(&arrived, n - 1));
-    tree.boxes = boxes;
-    tree.val = vals;
-    BCK(hipMemsetAsync(arrived, 0, (size_t)(n - 1) * sizeof(uint32_t), stream));
+    tree.leaf_box = pyr_base;
+    tree.max_leaf = max_leaf;
     hipLaunchKernelGGL(k_hier, dim3(blocks_for(n - 1)), dim3(BT), 0, stream, keys, n, tree, g);
     BCK(hipGetLastError());
-    hipLaunchKernelGGL(k_fit, dim3(blocks_for(n)), dim3(BT), 0, stream, n, tree, arrived);
+    {
+        uint32_t m = n;
+        for (uint32_t k = 1; k < pyr.levels; ++k) {
+            const uint32_t m2 = (m + 1) >> 1;
+            hipLaunchKernelGGL(k_pyramid, dim3(blocks_for(m2)), dim3(BT), 0, stream, pyr_base + pyr.off[k - 1], m, pyr_base + pyr.off[k], m2);
+            BCK(hipGetLastError());
+            m = m2;
+        }
+    }
+    hipLaunchKernelGGL(k_fit, dim3(blocks_for(n - 1)), dim3(BT), 0, stream, n, tree, pyr);
     BCK(hipGetLastError());
     BCK(hipMemcpyAsync(&h, g, sizeof h, hipMemcpyDeviceToHost, stream));
     BCK(hipStreamSynchronize(stream));
-    const uint32_t n_big = h.n_big;   // the root is one of them (n > MAX_LEAF)
+    mark("gather + tree + fit");
+    const uint32_t n_big = h.n_big;   // the root is one of them (n > max_leaf)
     if (n_big == 0 || n_big > n - 1) {
         if (err) *err = "device build: inner-node count out of range";
         return hipErrorUnknown;
@@ -417,6 +441,7 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
         BCK(hipMemcpyAsync(&g->q_count[cur], &h.q_count[cur], sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         cur ^= 1;
     }
+    mark("collapse");
     out->n_nodes = h.n_nodes;
     out->depth = depth;
     out->root_ref = node_base;   // 4-wide node 0 of this object

@@ -57,50 +57,53 @@ int main(int argc, char** argv) {
         if (keys[s] >> 63) return fail("key uses bit 63", s);
     if (n <= lbvh::MAX_LEAF) { std::printf("ok n=%u single leaf\n", n); return 0; }
 
+    // k_gather: boxes in sorted order = level 0 of the pyramid; k_pyramid: the levels above
+    lbvh::Pyramid pyr{};
+    const uint32_t pyr_total = lbvh::pyramid_layout(n, pyr.off, &pyr.levels);
+    std::vector<Box3> pyr_store(pyr_total);
+    for (uint32_t s = 0; s < n; ++s) pyr_store[s] = boxes[val[s]];
+    {
+        uint32_t m = n;
+        for (uint32_t k = 1; k < pyr.levels; ++k) {
+            uint32_t m2 = (m + 1) >> 1;
+            for (uint32_t j = 0; j < m2; ++j) pyr_store[pyr.off[k] + j] = lbvh::pyramid_pair(&pyr_store[pyr.off[k - 1]], m, j);
+            m = m2;
+        }
+        if (m != 1) return fail("pyramid does not end in one entry", m);
+    }
+    pyr.base = pyr_store.data();
+
     // k_hier
-    std::vector<uint32_t> child_l(n - 1), child_r(n - 1), first(n - 1), last(n - 1), parent_inner(n - 1, 12345u), parent_leaf(n, 12345u);
+    std::vector<uint32_t> child_l(n - 1), child_r(n - 1), first(n - 1), last(n - 1);
     std::vector<Box3> ibox(n - 1);
-    lbvh::Tree t{child_l.data(), child_r.data(), first.data(), last.data(), parent_inner.data(), parent_leaf.data(), ibox.data(),
-                 boxes.data(), val.data()};
+    lbvh::Tree t{child_l.data(), child_r.data(), first.data(), last.data(), ibox.data(), pyr_store.data(), lbvh::MAX_LEAF};
     for (uint32_t i = 0; i + 1 < n; ++i) lbvh::build_inner(keys.data(), n, i, t);
-    if (parent_inner[0] != lbvh::NONE) return fail("root has a parent");
     if (first[0] != 0 || last[0] != n - 1) return fail("root range", first[0], last[0]);
+    std::vector<uint32_t> parents(n - 1, 0), leaf_parents(n, 0);
     for (uint32_t i = 0; i + 1 < n; ++i) {
         // children partition the range
         uint32_t l = child_l[i], r = child_r[i];
         uint32_t lf = (l & lbvh::LEAF_BIT) ? (l & ~lbvh::LEAF_BIT) : first[l], ll = (l & lbvh::LEAF_BIT) ? (l & ~lbvh::LEAF_BIT) : last[l];
         uint32_t rf = (r & lbvh::LEAF_BIT) ? (r & ~lbvh::LEAF_BIT) : first[r], rl = (r & lbvh::LEAF_BIT) ? (r & ~lbvh::LEAF_BIT) : last[r];
         if (lf != first[i] || rl != last[i] || ll + 1 != rf) return fail("children do not partition the range", i);
-        if (!(l & lbvh::LEAF_BIT) && parent_inner[l] != i) return fail("parent of left", i);
-        if (!(r & lbvh::LEAF_BIT) && parent_inner[r] != i) return fail("parent of right", i);
-        if ((l & lbvh::LEAF_BIT) && parent_leaf[l & ~lbvh::LEAF_BIT] != i) return fail("parent of left leaf", i);
-        if ((r & lbvh::LEAF_BIT) && parent_leaf[r & ~lbvh::LEAF_BIT] != i) return fail("parent of right leaf", i);
-    }
-    // k_fit: the leaves in a shuffled order, each walking up as the kernel's threads do
-    std::vector<uint32_t> arrived(n - 1, 0), order(n);
-    std::iota(order.begin(), order.end(), 0u);
-    std::shuffle(order.begin(), order.end(), rng);
-    uint32_t max_walk = 0;
-    for (uint32_t s : order) {
-        Box3 box = boxes[val[s]];
-        uint32_t me = lbvh::LEAF_BIT | s, p = parent_leaf[s], walk = 0;
-        while (p != lbvh::NONE) {
-            if (arrived[p]++ == 0) break;
-            uint32_t l = child_l[p], r = child_r[p];
-            uint32_t sib = (l == me) ? r : l;
-            if (sib == me) return fail("sibling is self", p);
-            Box3 sb = (sib & lbvh::LEAF_BIT) ? boxes[val[sib & ~lbvh::LEAF_BIT]] : ibox[sib];
-            box = lbvh::box_union(box, sb);
-            ibox[p] = box;
-            me = p;
-            p = parent_inner[p];
-            ++walk;
+        for (uint32_t c : {l, r}) {
+            if (c & lbvh::LEAF_BIT) leaf_parents[c & ~lbvh::LEAF_BIT]++;
+            else parents[c]++;
         }
-        max_walk = std::max(max_walk, walk);
     }
-    for (uint32_t i = 0; i + 1 < n; ++i)
-        if (arrived[i] != 2) return fail("inner node not reached twice", i, arrived[i]);
-
+    if (parents[0] != 0) return fail("root has a parent");
+    for (uint32_t i = 1; i + 1 < n; ++i)
+        if (parents[i] != 1) return fail("inner node without exactly one parent", i, parents[i]);
+    for (uint32_t s = 0; s < n; ++s)
+        if (leaf_parents[s] != 1) return fail("leaf without exactly one parent", s, leaf_parents[s]);
+    // k_fit: range unions; must equal the exact union of the range, computed here the slow way for a sample of nodes
+    for (uint32_t i = 0; i + 1 < n; ++i) ibox[i] = lbvh::range_box(pyr, first[i], last[i]);
+    for (uint32_t i = 0; i + 1 < n; i += (n > 5000 ? 97 : 1)) {
+        if (last[i] - first[i] > 20000 && i != 0) continue;
+        Box3 e = pyr_store[first[i]];
+        for (uint32_t s = first[i] + 1; s <= last[i]; ++s) e = lbvh::box_union(e, pyr_store[s]);
+        if (std::memcmp(&e, &ibox[i], sizeof e) != 0) return fail("range union differs from the exact union", i);
+    }
     // k_collapse, level by level
     uint32_t n_big = 0;
     for (uint32_t i = 0; i + 1 < n; ++i) n_big += (last[i] - first[i] + 1 > lbvh::MAX_LEAF);
@@ -168,7 +171,7 @@ int main(int argc, char** argv) {
     }
     for (uint32_t s = 0; s < n; ++s)
         if (!seen[s]) return fail("slot in no leaf", s);
-    std::printf("ok n=%u nodes=%u (bound %u) depth=%u leaves=%zu tris/leaf=%.2f max_walk=%u\n", n, n_nodes, n_big, depth, leaves,
-                (double)tri_in_leaves / (double)leaves, max_walk);
+    std::printf("ok n=%u nodes=%u (bound %u) depth=%u leaves=%zu tris/leaf=%.2f\n", n, n_nodes, n_big, depth, leaves,
+                (double)tri_in_leaves / (double)leaves);
     return 0;
 }
