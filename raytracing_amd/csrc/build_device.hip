@@ -47,7 +47,6 @@ struct Globals {            // one small device record per build, zero-initialis
     uint32_t n_live;
     uint32_t n_big;         // inner nodes of the binary tree over more than MAX_LEAF triangles (bound on the 4-wide nodes)
     uint32_t n_nodes;       // 4-wide nodes allocated so far
-    uint32_t q_count[2];    // items in the two collapse queues
 };
 
 __device__ inline void load_raw(const float* raw, uint32_t t, float f[24]) {
@@ -195,15 +194,35 @@ __global__ void __launch_bounds__(BT) k_fit(uint32_t n, lbvh::Tree tree, lbvh::P
 }
 
 // One level of the top-down collapse: every queue item (binary inner node, index of its 4-wide node) writes its node
-// and queues the children that are inner nodes of the 4-wide tree.
+// and queues the children that are inner nodes of the 4-wide tree.  Node indices are handed out in level order, one
+// atomic per wavefront (a prefix sum over the lanes' child counts), and a child's place in the next level's queue is
+// its node index minus the first index of that level -- no second counter.
 __global__ void __launch_bounds__(BT) k_collapse(const uint2* __restrict__ q_in, uint32_t n_in, uint2* __restrict__ q_out,
-                                                 uint32_t q_cap, uint32_t which_out, lbvh::Tree tree, Node4* __restrict__ nodes,
-                                                 uint32_t node_cap, uint32_t node_base, uint32_t slot_base, Globals* g) {
+                                                 uint32_t level_base, lbvh::Tree tree, Node4* __restrict__ nodes, uint32_t node_cap,
+                                                 uint32_t node_base, uint32_t slot_base, Globals* g) {
     const uint32_t i = blockIdx.x * BT + threadIdx.x;
-    if (i >= n_in) return;
-    const uint2 item = q_in[i];
-    uint32_t kids[4];
-    const int nk = lbvh::collapse_children(tree, item.x, kids);
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool valid = i < n_in;
+    uint2 item = make_uint2(0u, 0u);
+    uint32_t kids[4] = {0u, 0u, 0u, 0u};
+    int nk = 0;
+    uint32_t c = 0;   // children of mine that become 4-wide nodes
+    if (valid) {
+        item = q_in[i];
+        nk = lbvh::collapse_children(tree, item.x, kids);
+        for (int k = 0; k < nk; ++k) c += lbvh::leaf_like(tree, kids[k]) ? 0u : 1u;
+    }
+    uint32_t incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 63u && total) base = atomicAdd(&g->n_nodes, total);
+    base = __shfl(base, 63, 64);
+    if (!valid) return;
+    uint32_t next = base + incl - c;
     Node4 nd;
     for (int k = 0; k < 4; ++k) {
         nd.pad[k] = 0;
@@ -212,13 +231,12 @@ __global__ void __launch_bounds__(BT) k_collapse(const uint2* __restrict__ q_in,
         if (lbvh::leaf_like(tree, kids[k])) {
             nd.child[k] = lbvh::leaf_ref_of(tree, kids[k], slot_base);
         } else {
-            const uint32_t idx = atomicAdd(&g->n_nodes, 1u);
-            const uint32_t qp = atomicAdd(&g->q_count[which_out], 1u);
-            if (idx < node_cap && qp < q_cap) {
-                q_out[qp] = make_uint2(kids[k], idx);
+            const uint32_t idx = next++;
+            if (idx < node_cap && idx >= level_base) {
+                q_out[idx - level_base] = make_uint2(kids[k], idx);
                 nd.child[k] = node_base + idx;
             } else {
-                nd.child[k] = REF_EMPTY;   // cannot happen (both are sized by n_big); the host checks the counters
+                nd.child[k] = REF_EMPTY;   // cannot happen (node_cap = n_big bounds the node count); the host checks n_nodes
             }
         }
     }
@@ -416,10 +434,8 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
     const uint2 root_item = make_uint2(0u, 0u);
     BCK(hipMemcpyAsync(q[0], &root_item, sizeof root_item, hipMemcpyHostToDevice, stream));
     h.n_nodes = 1;
-    h.q_count[0] = 1;
-    h.q_count[1] = 0;
     BCK(hipMemcpyAsync(g, &h, sizeof h, hipMemcpyHostToDevice, stream));
-    uint32_t n_in = 1, depth = 0;
+    uint32_t n_in = 1, depth = 0, level_base = 1;   // level_base: index of the first node the level's children get
     int cur = 0;
     while (n_in > 0) {
         ++depth;
@@ -427,18 +443,17 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
             if (err) *err = "device build: collapse did not terminate";
             return hipErrorUnknown;
         }
-        hipLaunchKernelGGL(k_collapse, dim3(blocks_for(n_in)), dim3(BT), 0, stream, q[cur], n_in, q[cur ^ 1], n_big, (uint32_t)(cur ^ 1),
-                           tree, nodes, n_big, node_base, slot_base, g);
+        hipLaunchKernelGGL(k_collapse, dim3(blocks_for(n_in)), dim3(BT), 0, stream, q[cur], n_in, q[cur ^ 1], level_base, tree, nodes, n_big,
+                           node_base, slot_base, g);
         BCK(hipGetLastError());
         BCK(hipMemcpyAsync(&h, g, sizeof h, hipMemcpyDeviceToHost, stream));
         BCK(hipStreamSynchronize(stream));
-        if (h.n_nodes > n_big || h.q_count[cur ^ 1] > n_big) {
-            if (err) *err = "device build: node queue overflow";
+        if (h.n_nodes > n_big || h.n_nodes < level_base) {
+            if (err) *err = "device build: node count out of range";
             return hipErrorUnknown;
         }
-        n_in = h.q_count[cur ^ 1];
-        h.q_count[cur] = 0;   // this level's input queue is the next level's output queue
-        BCK(hipMemcpyAsync(&g->q_count[cur], &h.q_count[cur], sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        n_in = h.n_nodes - level_base;
+        level_base = h.n_nodes;
         cur ^= 1;
     }
     mark("collapse");
