@@ -160,7 +160,9 @@ typedef struct trr_scene_info {
     uint64_t n_triangles_live;   /* of those, in the tree (|ab x ac| > 0, triangle.rs:56) */
     uint64_t n_nodes;            /* 128-B 4-wide nodes */
     uint32_t bvh_depth;          /* levels of the deepest object tree (root = 1) */
+    uint32_t stack_need;         /* traversal stack entries the tree can need; trr_scene_create* refuses more than 64 */
     uint32_t build;              /* TRR_BUILD_* */
+    uint32_t pad;
     double ms_build;             /* wall time of the flattening + BVH build + upload */
 } trr_scene_info;
 int trr_scene_get_info(const trr_scene* scene, trr_scene_info* out);

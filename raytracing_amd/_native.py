@@ -71,7 +71,8 @@ class Stats(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_triangles", C.c_uint64), ("n_triangles_live", C.c_uint64), ("n_nodes", C.c_uint64),
-                ("bvh_depth", C.c_uint32), ("build", C.c_uint32), ("ms_build", C.c_double)]
+                ("bvh_depth", C.c_uint32), ("stack_need", C.c_uint32), ("build", C.c_uint32), ("pad", C.c_uint32),
+                ("ms_build", C.c_double)]
 
     def as_dict(self) -> dict:
         return {n: getattr(self, n) for n, _ in self._fields_}

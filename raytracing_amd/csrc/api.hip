@@ -97,6 +97,7 @@ struct trr_scene {
     uint32_t n_objs = 0, n_lights = 0, n_mats = 0, n_tex = 0;
     uint64_t n_nodes = 0, n_tris_total = 0, n_tris_live = 0;
     uint32_t bvh_depth = 0;
+    uint32_t stack_need = 0;
     uint32_t build = TRR_BUILD_HOST;
     double ms_build = 0.0;
     trr_settings settings{};
@@ -356,7 +357,7 @@ static int build_scene_device(trr_ctx* ctx, trr_scene* sc, const trr_object_desc
     int rc = ensure(ctx, sc->interp, (size_t)sc->n_tris_total * sizeof(InterpRec));
     if (rc != TRR_OK) return rc;
     uint64_t node_base = 0, slot_base = 0, interp_base = 0;
-    uint32_t depth_max = 0;
+    uint32_t depth_max = 0, stack_max = 0;
     sc->h_objs.assign(n_objects, ObjRec{});
     for (uint32_t oi = 0; oi < n_objects; ++oi) {
         const trr_object_desc& d = objects[oi];
@@ -381,6 +382,7 @@ static int build_scene_device(trr_ctx* ctx, trr_scene* sc, const trr_object_desc
         o.flags = (d.n_triangles == 1) ? 1u : 0u;   // [crate] a root Leaf is returned by traverse() without a box test
         o.slack_abs = 1.0e-4f * parts[oi].maxabs;
         depth_max = std::max(depth_max, parts[oi].depth);
+        stack_max = std::max(stack_max, parts[oi].stack_need);
         node_base += parts[oi].n_nodes;
         slot_base += parts[oi].n_live;
         interp_base += d.n_triangles;
@@ -408,6 +410,7 @@ static int build_scene_device(trr_ctx* ctx, trr_scene* sc, const trr_object_desc
     sc->n_nodes = node_base;
     sc->n_tris_live = slot_base;
     sc->bvh_depth = depth_max;
+    sc->stack_need = stack_max;
     return TRR_OK;
 }
 
@@ -431,7 +434,7 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
     std::vector<InterpRec> interp;
     std::vector<ObjRec> objs(n_objects);
     std::vector<MatRec> mats;
-    uint32_t depth_max = 0;
+    uint32_t depth_max = 0, stack_max = 0;
     uint64_t n_total = 0;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
 
@@ -550,6 +553,7 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
         o.flags = (nt == 1) ? 1u : 0u;   // [crate] a root Leaf is returned by traverse() without a box test
         o.slack_abs = 1.0e-4f * maxabs;
         depth_max = std::max(depth_max, br.max_depth);
+        stack_max = std::max(stack_max, br.stack_need);
     }
     // leaf references hold the first triangle slot in 29 bits, and the two highest 32-bit values are REF_EMPTY and the
     // trace kernel's "idle lane" marker; node indices must stay below REF_LEAF
@@ -564,6 +568,7 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
     sc->n_tris_total = n_total;
     sc->n_tris_live = tris.size();
     sc->bvh_depth = depth_max;
+    sc->stack_need = stack_max;
     sc->n_mats = (uint32_t)mats.size();
     sc->n_tex = n_textures;
     // texture atlas
@@ -594,6 +599,10 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
             (rc = upload(ctx, sc->tris, tris.data(), tris.size() * sizeof(TriRec))) == TRR_OK)
             rc = upload(ctx, sc->interp, interp.data(), interp.size() * sizeof(InterpRec));
     }
+    if (rc == TRR_OK && sc->stack_need > (uint32_t)TRACE_STACK_ENTRIES)
+        rc = fail(ctx, TRR_ERR_INVALID, "trr_scene_create: the BVH can need a traversal stack of " + std::to_string(sc->stack_need) +
+                                            " entries, the trace kernel holds " + std::to_string(TRACE_STACK_ENTRIES) +
+                                            (build == TRR_BUILD_DEVICE ? " (build this scene with TRR_BUILD_HOST)" : ""));
     if (rc == TRR_OK) rc = upload(ctx, sc->objs, sc->h_objs.data(), sc->h_objs.size() * sizeof(ObjRec));
     if (rc != TRR_OK) {
         trr_scene_destroy(sc);
@@ -611,6 +620,7 @@ int trr_scene_get_info(const trr_scene* sc, trr_scene_info* out) {
     out->n_triangles_live = sc->n_tris_live;
     out->n_nodes = sc->n_nodes;
     out->bvh_depth = sc->bvh_depth;
+    out->stack_need = sc->stack_need;
     out->build = sc->build;
     out->ms_build = sc->ms_build;
     return TRR_OK;

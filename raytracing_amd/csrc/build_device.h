@@ -18,6 +18,7 @@ struct DeviceBuildOut {
     uint32_t n_live = 0;
     uint32_t root_ref = REF_EMPTY;   // absolute reference (node_base / slot_base applied)
     uint32_t depth = 0;              // levels of the 4-wide tree (root = 1)
+    uint32_t stack_need = 0;         // traversal stack entries the tree can need (device_types.h)
     float maxabs = 0.0f;             // largest finite |coordinate| (ObjRec::slack_abs)
 };
 

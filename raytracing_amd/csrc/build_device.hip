@@ -47,6 +47,7 @@ struct Globals {            // one small device record per build, zero-initialis
     uint32_t n_live;
     uint32_t n_big;         // inner nodes of the binary tree over more than MAX_LEAF triangles (bound on the 4-wide nodes)
     uint32_t n_nodes;       // 4-wide nodes allocated so far
+    uint32_t stack_need;    // traversal stack entries the tree can need (device_types.h, TRACE_STACK_ENTRIES)
 };
 
 __device__ inline void load_raw(const float* raw, uint32_t t, float f[24]) {
@@ -197,8 +198,8 @@ __global__ void __launch_bounds__(BT) k_fit(uint32_t n, lbvh::Tree tree, lbvh::P
 // and queues the children that are inner nodes of the 4-wide tree.  Node indices are handed out in level order, one
 // atomic per wavefront (a prefix sum over the lanes' child counts), and a child's place in the next level's queue is
 // its node index minus the first index of that level -- no second counter.
-__global__ void __launch_bounds__(BT) k_collapse(const uint2* __restrict__ q_in, uint32_t n_in, uint2* __restrict__ q_out,
-                                                 uint32_t level_base, lbvh::Tree tree, Node4* __restrict__ nodes, uint32_t node_cap,
+__global__ void __launch_bounds__(BT) k_collapse(const uint2* __restrict__ q_in, const uint32_t* __restrict__ pushed_in, uint32_t n_in,
+                                                 uint2* __restrict__ q_out, uint32_t* __restrict__ pushed_out, uint32_t level_base, lbvh::Tree tree, Node4* __restrict__ nodes, uint32_t node_cap,
                                                  uint32_t node_base, uint32_t slot_base, Globals* g) {
     const uint32_t i = blockIdx.x * BT + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -206,12 +207,17 @@ __global__ void __launch_bounds__(BT) k_collapse(const uint2* __restrict__ q_in,
     uint2 item = make_uint2(0u, 0u);
     uint32_t kids[4] = {0u, 0u, 0u, 0u};
     int nk = 0;
-    uint32_t c = 0;   // children of mine that become 4-wide nodes
+    uint32_t c = 0;        // children of mine that become 4-wide nodes
+    uint32_t pushed = 0;   // stack entries a traversal may hold while it is below this node (bvh.cpp, Collapser)
     if (valid) {
         item = q_in[i];
         nk = lbvh::collapse_children(tree, item.x, kids);
         for (int k = 0; k < nk; ++k) c += lbvh::leaf_like(tree, kids[k]) ? 0u : 1u;
+        pushed = pushed_in[i] + (uint32_t)nk - 1u;
     }
+    uint32_t wmax = pushed;
+    for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor(wmax, o, 64));
+    if (lane == 0u && wmax) atomicMax(&g->stack_need, wmax);
     uint32_t incl = c;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = __shfl_up(incl, o, 64);
@@ -234,6 +240,7 @@ __global__ void __launch_bounds__(BT) k_collapse(const uint2* __restrict__ q_in,
             const uint32_t idx = next++;
             if (idx < node_cap && idx >= level_base) {
                 q_out[idx - level_base] = make_uint2(kids[k], idx);
+                pushed_out[idx - level_base] = pushed;
                 nd.child[k] = node_base + idx;
             } else {
                 nd.child[k] = REF_EMPTY;   // cannot happen (node_cap = n_big bounds the node count); the host checks n_nodes
@@ -427,9 +434,13 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
 
     Node4* nodes = nullptr;
     uint2* q[2] = {nullptr, nullptr};
+    uint32_t* q_pushed[2] = {nullptr, nullptr};
     BCK(tmp.get(&nodes, n_big));
     BCK(tmp.get(&q[0], n_big));
     BCK(tmp.get(&q[1], n_big));
+    BCK(tmp.get(&q_pushed[0], n_big));
+    BCK(tmp.get(&q_pushed[1], n_big));
+    BCK(hipMemsetAsync(q_pushed[0], 0, sizeof(uint32_t), stream));
     // level 1: the root of the binary tree becomes 4-wide node 0
     const uint2 root_item = make_uint2(0u, 0u);
     BCK(hipMemcpyAsync(q[0], &root_item, sizeof root_item, hipMemcpyHostToDevice, stream));
@@ -443,8 +454,8 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
             if (err) *err = "device build: collapse did not terminate";
             return hipErrorUnknown;
         }
-        hipLaunchKernelGGL(k_collapse, dim3(blocks_for(n_in)), dim3(BT), 0, stream, q[cur], n_in, q[cur ^ 1], level_base, tree, nodes, n_big,
-                           node_base, slot_base, g);
+        hipLaunchKernelGGL(k_collapse, dim3(blocks_for(n_in)), dim3(BT), 0, stream, q[cur], q_pushed[cur], n_in, q[cur ^ 1], q_pushed[cur ^ 1],
+                           level_base, tree, nodes, n_big, node_base, slot_base, g);
         BCK(hipGetLastError());
         BCK(hipMemcpyAsync(&h, g, sizeof h, hipMemcpyDeviceToHost, stream));
         BCK(hipStreamSynchronize(stream));
@@ -458,6 +469,7 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
     }
     mark("collapse");
     out->n_nodes = h.n_nodes;
+    out->stack_need = h.stack_need;
     out->depth = depth;
     out->root_ref = node_base;   // 4-wide node 0 of this object
     out->nodes = nodes;

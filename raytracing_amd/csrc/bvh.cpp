@@ -161,15 +161,17 @@ struct Collapser {
     const std::vector<BNode>& bn;
     std::vector<Node4>& out;
     uint32_t max_depth = 0;
+    uint32_t stack_need = 0;
 
-    uint32_t ref_of(uint32_t b, uint32_t depth) {
+    uint32_t ref_of(uint32_t b, uint32_t depth, uint32_t pushed) {
         const BNode& nd = bn[b];
         if (nd.count > 0) return make_leaf_ref(nd.first, nd.count);
-        return emit(b, depth);
+        return emit(b, depth, pushed);
     }
 
     // emits the 4-wide node whose children are (grand)children of binary node b; returns its index
-    uint32_t emit(uint32_t b, uint32_t depth) {
+    // pushed: entries the traversal may hold on its stack when it arrives at this node
+    uint32_t emit(uint32_t b, uint32_t depth, uint32_t pushed) {
         if (depth > max_depth) max_depth = depth;
         uint32_t me = (uint32_t)out.size();
         out.emplace_back();
@@ -206,7 +208,9 @@ struct Collapser {
                 nd.child[k] = REF_EMPTY;
             }
         }
-        for (int k = 0; k < nk; ++k) nd.child[k] = ref_of(kids[k], depth + 1);
+        pushed += (uint32_t)nk - 1u;   // the node pushes all but the child it descends into
+        if (pushed > stack_need) stack_need = pushed;
+        for (int k = 0; k < nk; ++k) nd.child[k] = ref_of(kids[k], depth + 1, pushed);
         out[me] = nd;
         return me;
     }
@@ -219,6 +223,7 @@ void build_bvh4(const Box3* boxes, uint32_t n, uint32_t n_threads, BuildResult* 
     res->order.clear();
     res->root_ref = REF_EMPTY;
     res->max_depth = 0;
+    res->stack_need = 0;
     res->bounds = empty_box();
     if (n == 0) return;
     if (const char* e = std::getenv("TRR_BVH_MAX_LEAF")) MAX_LEAF = (uint32_t)std::min(4, std::max(1, std::atoi(e)));
@@ -254,8 +259,9 @@ void build_bvh4(const Box3* boxes, uint32_t n, uint32_t n_threads, BuildResult* 
     }
     res->nodes.reserve((size_t)n / 2 + 16);
     Collapser c{b.nodes, res->nodes};
-    res->root_ref = c.emit(0, 1);
+    res->root_ref = c.emit(0, 1, 0);
     res->max_depth = c.max_depth;
+    res->stack_need = c.stack_need;
 }
 
 }   // namespace trr

@@ -34,6 +34,7 @@ struct BuildResult {
     std::vector<uint32_t> order;   // slot -> index into the input box array
     uint32_t root_ref = REF_EMPTY; // inner node index, leaf reference, or REF_EMPTY
     uint32_t max_depth = 0;        // depth of the 4-wide tree (root = 1)
+    uint32_t stack_need = 0;       // traversal stack entries the tree can need (device_types.h, TRACE_STACK_ENTRIES)
     Box3 bounds{};                 // union of all input boxes
 };
 

@@ -6,6 +6,11 @@
 
 namespace trr {
 
+// Entries of the trace kernel's per-lane traversal stack (LDS part + HBM spill part, kernels.hip).  A 4-wide node pushes
+// at most children-1 entries before descending, so a tree needs max over its inner nodes of (sum of children-1 over the
+// node's ancestors and itself) entries; both builders compute that figure and trr_scene_create refuses a tree above it.
+constexpr int TRACE_STACK_ENTRIES = 64;
+
 // 64-byte leaf-ordered triangle record = what one exact test reads (half a 128-B line; a 4-triangle leaf is
 // two whole lines).  n = (b-a)x(c-a) / |.| and len = |(b-a)x(c-a)| are the values Triangle::intersect
 // recomputes on every call (src/scene/triangle.rs:54-56), precomputed once with identical fp32 operations.

@@ -173,7 +173,7 @@ constexpr uint8_t NLEV_PENDING = 0xFF;   // nlev value of a camera sample whose 
 #define TRR_STACK_LDS 12
 #endif
 constexpr int STACK_LDS = TRR_STACK_LDS;       // per-lane (ref, tmin) entries kept in LDS
-constexpr int STACK_SPILL = 64 - STACK_LDS;     // further entries in a per-thread HBM spill area (rarely touched)
+constexpr int STACK_SPILL = TRACE_STACK_ENTRIES - STACK_LDS;     // further entries in a per-thread HBM spill area (rarely touched)
 #ifndef TRR_REFILL_MIN
 #define TRR_REFILL_MIN 36
 #endif
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
         uint2 e = make_uint2(ref, __float_as_uint(tmin));
         if (sp < STACK_LDS) s_stack[sp * TRACE_THREADS + tid] = e;
         else if (sp < STACK_LDS + STACK_SPILL) my_spill[sp - STACK_LDS] = e;
-        else return;   // unreachable for trees built by bvh.cpp (depth-bounded); drop rather than corrupt
+        else return;   // unreachable: trr_scene_create refuses trees whose stack need exceeds TRACE_STACK_ENTRIES
         ++sp;
     };
     auto pop = [&]() -> uint32_t {

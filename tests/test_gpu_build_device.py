@@ -110,6 +110,36 @@ def test_million_triangle_build_validates_and_renders_the_same(ctx):
           f"device {di['ms_build']:.1f} (depth {di['bvh_depth']}, {di['n_nodes']} nodes)")
 
 
+def test_stack_need_is_reported_and_bounded(ctx, oracle_mod):
+    """A one-sided tree: triangle centres on a geometric series along the diagonal (every Morton bit splits off one
+    triangle) plus a cluster of identical triangles at its small end.  Either the upload reports a traversal-stack need
+    within the kernel's 64 entries and renders what the oracle renders, or it refuses the tree -- never a silent overflow."""
+    rows = []
+    for k in range(40):
+        c = 4.0 * 0.5 ** k
+        rows.append(((c - 1.5, c - 1.5 - 0.3, -4 - c), (c - 1.5 + 0.3, c - 1.5 - 0.3, -4 - c), (c - 1.5, c - 1.5 + 0.3, -4 - c)))
+    rows += [((-1.5, -1.8, -4.0), (-1.2, -1.8, -4.0), (-1.5, -1.2, -4.0))] * 150
+    tri = tri_rows(*rows)
+    obj = Object(triangles=tri, material_index=np.zeros(len(tri), np.int32), materials=[mat(kd=(0.7, 0.6, 0.5), illum=2, ks=(1, 1, 1), ns=8.0, dissolve=0.0)])
+    sc = Scene(objects=[obj], lights=[Light(np.array([0.0, 3.0, 0.0], F32), np.array([1, 1, 1], F32), 20.0)],
+               camera=front_camera(96, 72), settings=Settings())
+    for build in ("host", "device"):
+        try:
+            rt = Raytracer(sc, context=ctx, build=build)
+        except N.NativeError as e:
+            assert "traversal stack" in str(e)
+            continue
+        try:
+            info = rt.scene_info()
+            assert 1 <= info["stack_need"] <= 64 and info["stack_need"] <= 3 * info["bvh_depth"], info
+            rt.validate()
+            out = rt.render_frame(want_ids=True)
+        finally:
+            rt.close()
+        assert_parity(out, oracle_mod.OracleScene(sc).render(), what=f"one-sided tree, {build} build")
+        print(f"\n{build}: depth {info['bvh_depth']}, stack need {info['stack_need']}")
+
+
 def test_unknown_build_mode_is_rejected(ctx):
     import ctypes as C
     h = C.c_void_p()
