@@ -26,6 +26,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <memory>
 #include <optional>
@@ -271,6 +272,24 @@ public:
         return true;
     }
 
+    // Progressive form (the sink of render.rs:155-186): sink(x_block, y_block, block_w, block_h, rgb) once per finished
+    // block, batches of blocks_per_batch blocks (0 = one row of the 20x20 grid) in row-major block order; rgb is valid
+    // only during the call.  Returns false when cancelled.
+    using BlockSink = std::function<void(uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t*)>;
+    bool render_blocks(const BlockSink& sink, uint32_t blocks_per_batch = 0, const std::atomic<int32_t>* cancel = nullptr,
+                       const std::function<void(uint32_t, uint32_t)>* progress = nullptr, trr_stats* stats = nullptr) {
+        struct User { const BlockSink* sink; const std::function<void(uint32_t, uint32_t)>* progress; } u{&sink, progress};
+        auto on_block = [](void* user, uint32_t xb, uint32_t yb, uint32_t bw, uint32_t bh, const uint8_t* rgb) {
+            (*static_cast<User*>(user)->sink)(xb, yb, bw, bh, rgb);
+        };
+        auto on_progress = [](void* user, uint32_t done, uint32_t total) { (*static_cast<User*>(user)->progress)(done, total); };
+        int rc = trr_render_blocks(ctx_->get(), scene_, delta_, max_depth_, 0, blocks_per_batch,
+                                   reinterpret_cast<const volatile int32_t*>(cancel), +on_block, progress ? +on_progress : nullptr, &u, stats);
+        if (rc == TRR_ERR_CANCELLED) return false;
+        ctx_->check(rc);
+        return true;
+    }
+
 private:
     void upload(const Scene& scene) {
         std::vector<trr_object_desc> objs(scene.objects.size());
@@ -350,7 +369,9 @@ public:
     bool finished() const { return progress.load() == UINT16_MAX; }
 
     // Render::render (render.rs:39-71): resets the handle and spawns the render thread on a copy of the scene
-    void render(Scene scene, float delta = 1e-5f, uint32_t max_depth = 5) {
+    // image fills block by block while the thread runs (the reference's sink paints every finished block into it,
+    // render.rs:170-183); blocks_per_batch = blocks that appear together (0 = one row of blocks)
+    void render(Scene scene, float delta = 1e-5f, uint32_t max_depth = 5, uint32_t blocks_per_batch = 0) {
         if (thread) throw std::logic_error("a render is already in flight (ui/statusbar.rs:142-157 disables the button)");
         image.width = scene.camera.resolution.first;
         image.height = scene.camera.resolution.second;
@@ -358,14 +379,18 @@ public:
         progress = 0;                                                  // render.rs:54
         time = 0;                                                      // render.rs:55
         error.clear();
-        thread.emplace([this, scene = std::move(scene), delta, max_depth] {
+        thread.emplace([this, scene = std::move(scene), delta, max_depth, blocks_per_batch] {
             auto start = std::chrono::steady_clock::now();             // render.rs:96
             try {
                 Raytracer rt(ctx_, scene, delta, max_depth);
                 std::function<void(uint32_t, uint32_t)> on_progress = [this](uint32_t done, uint32_t total) {   // render.rs:143-149
                     progress = (uint16_t)std::lround(65535.0 * done / std::max(1u, total));
                 };
-                rt.render_frame(image.rgb.data(), &cancel, &on_progress);
+                Raytracer::BlockSink sink = [this](uint32_t xb, uint32_t yb, uint32_t bw, uint32_t bh, const uint8_t* rgb) {
+                    for (uint32_t y = 0; y < bh; ++y)                  // render.rs:170-183
+                        std::memcpy(&image.rgb[((size_t)(yb * bh + y) * image.width + (size_t)xb * bw) * 3], rgb + (size_t)y * bw * 3, (size_t)bw * 3);
+                };
+                rt.render_blocks(sink, blocks_per_batch, &cancel, &on_progress);
             } catch (const std::exception& e) {
                 error = e.what();
             }

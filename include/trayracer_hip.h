@@ -195,6 +195,19 @@ int trr_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, 
                uint8_t* rgb_out, uint32_t* hit_obj_out, uint32_t* hit_tri_out,
                const volatile int32_t* cancel_flag, trr_progress_cb progress, void* user, trr_stats* stats_out);
 
+/* Progressive form of trr_render: the reference's sink (render.rs:155-186) receives each finished block as
+ * (pixels, x_block, y_block) and paints it into the texture and the image while the render goes on.  The frame is
+ * rendered in batches of `blocks_per_batch` blocks (0 = one row of the 20x20 grid) in row-major block order, and after
+ * each batch `sink` is called once per block of it, on the calling thread: (x_block, y_block) are block coordinates as
+ * in render.rs:129-130, `rgb` holds block_w*block_h RGB8 pixels row-major inside the block and is valid only during the
+ * call.  Pixels of the remainder strip (render.rs:100-102) belong to no block and are never delivered.  `cancel_flag`
+ * is polled and `progress` (nullable) called between batches as in trr_render.  Smaller batches mean earlier blocks
+ * and a slower frame (every batch ends with the latency of its longest ray). */
+typedef void (*trr_block_cb)(void* user, uint32_t x_block, uint32_t y_block, uint32_t block_w, uint32_t block_h, const uint8_t* rgb);
+int trr_render_blocks(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t flags, uint32_t blocks_per_batch,
+                      const volatile int32_t* cancel_flag, trr_block_cb sink, trr_progress_cb progress, void* user,
+                      trr_stats* stats_out);
+
 /* Multi-GPU form: renders the blocks b with b % n_shards == shard (row-major block ids over the grid of
  * render.rs:109-110) into a compact DEVICE strip: block j-th owned -> bytes [j*bw*bh*3, (j+1)*bw*bh*3),
  * row-major inside the block.  All strips have trr_strip_bytes() bytes (the last block slot of a short

@@ -82,12 +82,13 @@ TRR_BUILD_HOST = 0
 TRR_BUILD_DEVICE = 1
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)
+BLOCK_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8))
 
 # every symbol include/trayracer_hip.h declares
 EXPORTS = [
     "trr_create", "trr_destroy", "trr_last_error", "trr_scene_create", "trr_scene_create_ex", "trr_scene_get_info",
     "trr_scene_validate", "trr_scene_destroy", "trr_scene_set_instances",
-    "trr_scene_set_lights", "trr_scene_set_settings", "trr_scene_set_camera", "trr_render", "trr_render_shard_device",
+    "trr_scene_set_lights", "trr_scene_set_settings", "trr_scene_set_camera", "trr_render", "trr_render_blocks", "trr_render_shard_device",
     "trr_strip_bytes", "trr_assemble_device", "trr_synchronize", "trr_collect_stats", "trr_object_matrices", "trr_camera_ray", "trr_version",
 ]
 
@@ -147,6 +148,8 @@ def lib() -> C.CDLL:
     L.trr_scene_set_camera.argtypes = [vp, vp]
     L.trr_render.restype = i32
     L.trr_render.argtypes = [vp, vp, f32, u32, u32, vp, vp, vp, vp, vp, vp, vp]
+    L.trr_render_blocks.restype = i32
+    L.trr_render_blocks.argtypes = [vp, vp, f32, u32, u32, u32, vp, vp, vp, vp, vp]
     L.trr_render_shard_device.restype = i32
     L.trr_render_shard_device.argtypes = [vp, vp, f32, u32, u32, u32, u32, vp, C.c_size_t, vp, vp, vp, vp, vp]
     L.trr_strip_bytes.restype = C.c_size_t

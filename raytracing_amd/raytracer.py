@@ -234,6 +234,28 @@ class Raytracer:
             N.check(rc, self.ctx.handle)
         return {"rgb": rgb, "hit_obj": ho, "hit_tri": ht, "stats": st, "cancelled": cancelled}
 
+    def render_blocks(self, sink, blocks_per_batch: int = 0, cancel_flag=None, progress=None, counters: bool = False):
+        """Progressive render (the sink of render.rs:155-186): ``sink(x_block, y_block, block)`` is called once per finished
+        block, ``block`` a [block_h, block_w, 3] uint8 array valid only during the call, batches of ``blocks_per_batch``
+        blocks (0 = one row of the 20x20 grid) in row-major block order.  Returns dict(stats, cancelled)."""
+        st = N.Stats()
+
+        def on_block(user, xb, yb, bw, bh, ptr):
+            sink(int(xb), int(yb), np.ctypeslib.as_array(ptr, shape=(bh, bw, 3)))
+
+        bcb = N.BLOCK_CB(on_block)
+        pcb = N.PROGRESS_CB(lambda user, done, total: progress(done, total)) if progress else None
+        rc = N.lib().trr_render_blocks(self.ctx.handle, self._scene, self.delta, self.max_depth,
+                                       N.TRR_FLAG_COUNTERS if counters else 0, int(blocks_per_batch),
+                                       C.addressof(cancel_flag) if cancel_flag is not None else None,
+                                       C.cast(bcb, C.c_void_p), C.cast(pcb, C.c_void_p) if pcb else None, None, C.addressof(st))
+        if rc == N.TRR_ERR_RESOLUTION:
+            raise ZeroDivisionError("resolution below 20 pixels: the reference divides by zero (render.rs:109)")
+        cancelled = rc == N.TRR_ERR_CANCELLED
+        if not cancelled:
+            N.check(rc, self.ctx.handle)
+        return {"stats": st, "cancelled": cancelled}
+
     def strip_bytes(self, n_shards: int) -> int:
         return int(N.lib().trr_strip_bytes(self.width, self.height, int(n_shards)))
 
@@ -284,7 +306,9 @@ class Render:
         self.error: Optional[BaseException] = None
         self._ctx = Context(device)
 
-    def render(self, scene: Scene, delta: float = DEFAULT_DELTA, max_depth: int = DEFAULT_MAX_DEPTH):
+    def render(self, scene: Scene, delta: float = DEFAULT_DELTA, max_depth: int = DEFAULT_MAX_DEPTH, blocks_per_batch: int = 0):
+        """``self.image`` fills block by block while the thread runs, as the reference's sink paints each finished block
+        into ``image`` (render.rs:170-183); ``blocks_per_batch`` = blocks that appear together (0 = one row of blocks)."""
         if self.thread is not None and self.thread.is_alive():
             raise RuntimeError("a render is already in flight (statusbar.rs:142-157 disables the button)")
         w, h = scene.camera.resolution
@@ -300,8 +324,12 @@ class Render:
                 try:
                     def on_progress(done, total):    # render.rs:143-149
                         self.progress = int(round(done / max(1, total) * 65535))
-                    out = rt.render_frame(cancel_flag=self.cancel, progress=on_progress)
-                    self.image = out["rgb"]
+                    image = self.image
+
+                    def sink(xb, yb, block):         # render.rs:170-183
+                        bh, bw = block.shape[:2]
+                        image[yb * bh:(yb + 1) * bh, xb * bw:(xb + 1) * bw] = block
+                    rt.render_blocks(sink, blocks_per_batch=blocks_per_batch, cancel_flag=self.cancel, progress=on_progress)
                 finally:
                     rt.close()
             except BaseException as e:   # the reference's render thread has no error channel; we keep one
