@@ -13,7 +13,9 @@
 namespace trr {
 namespace {
 
-constexpr int NBINS = 16;
+constexpr int MAX_BINS = 64;
+int NBINS = 16;              // (tunable for experiments: TRR_BVH_BINS = 4..64)
+uint32_t SWEEP_MAX = 0;      // ranges of at most this many triangles are split by an exact SAH sweep (TRR_BVH_SWEEP)
 uint32_t MAX_LEAF = 4;       // (tunable for experiments: TRR_BVH_MAX_LEAF = 1..4)
 uint32_t ALWAYS_LEAF = 2;    // ranges of at most this many triangles are never split (TRR_BVH_ALWAYS_LEAF)
 float LEAF_BIAS = 1.5f;      // leaf preferred while leaf_cost <= split_cost + LEAF_BIAS * area (TRR_BVH_LEAF_BIAS)
@@ -76,6 +78,41 @@ struct Builder {
         uint32_t cnt = hi - lo;
         if (cnt <= ALWAYS_LEAF) { make_leaf(nd, lo, hi); return; }
 
+        // exact SAH sweep for small ranges: every split position of the centroid order on every axis
+        if (cnt <= SWEEP_MAX && depth < 56) {
+            float sw_cost = INFINITY;
+            int sw_axis = -1;
+            uint32_t sw_pos = 0;
+            std::vector<uint32_t> order(idx.begin() + lo, idx.begin() + hi);
+            std::vector<float> rarea(cnt);
+            for (int ax = 0; ax < 3; ++ax) {
+                const std::vector<float>& ca = cent[ax];
+                std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ca[a] < ca[b] || (ca[a] == ca[b] && a < b); });
+                Box3 acc = empty_box();
+                for (uint32_t i = cnt; i-- > 1;) { grow(acc, boxes[order[i]]); rarea[i] = half_area(acc); }
+                acc = empty_box();
+                for (uint32_t i = 1; i < cnt; ++i) {
+                    grow(acc, boxes[order[i - 1]]);
+                    float cost = half_area(acc) * (float)i + rarea[i] * (float)(cnt - i);
+                    if (cost < sw_cost) { sw_cost = cost; sw_axis = ax; sw_pos = i; }
+                }
+            }
+            if (sw_axis >= 0) {
+                if (cnt <= MAX_LEAF) {
+                    float leaf_cost = half_area(box) * (float)cnt;
+                    if (leaf_cost <= sw_cost + LEAF_BIAS * half_area(box)) { make_leaf(nd, lo, hi); return; }
+                }
+                const std::vector<float>& ca = cent[sw_axis];
+                std::sort(idx.begin() + lo, idx.begin() + hi, [&](uint32_t a, uint32_t b) { return ca[a] < ca[b] || (ca[a] == ca[b] && a < b); });
+                uint32_t mid = lo + sw_pos;
+                uint32_t kids = alloc2();
+                nd.count = 0; nd.first = 0; nd.left = kids; nd.right = kids + 1;
+                build(kids, lo, mid, depth + 1);
+                build(kids + 1, mid, hi, depth + 1);
+                return;
+            }
+        }
+
         // binned SAH over the three axes
         float best_cost = INFINITY;
         int best_axis = -1, best_bin = -1;
@@ -85,8 +122,8 @@ struct Builder {
                 float ext = cmax[ax] - cmin[ax];
                 if (!(ext > 0.0f) || !std::isfinite(ext)) continue;
                 float scale = (float)NBINS / ext;
-                Box3 bb[NBINS];
-                uint32_t bc[NBINS];
+                Box3 bb[MAX_BINS];
+                uint32_t bc[MAX_BINS];
                 for (int b = 0; b < NBINS; ++b) { bb[b] = empty_box(); bc[b] = 0; }
                 for (uint32_t i = lo; i < hi; ++i) {
                     uint32_t t = idx[i];
@@ -95,8 +132,8 @@ struct Builder {
                     bc[b]++;
                     grow(bb[b], boxes[t]);
                 }
-                float right_area[NBINS];
-                uint32_t right_cnt[NBINS];
+                float right_area[MAX_BINS];
+                uint32_t right_cnt[MAX_BINS];
                 Box3 acc = empty_box();
                 uint32_t c = 0;
                 for (int b = NBINS - 1; b > 0; --b) {
@@ -229,6 +266,8 @@ void build_bvh4(const Box3* boxes, uint32_t n, uint32_t n_threads, BuildResult* 
     if (const char* e = std::getenv("TRR_BVH_MAX_LEAF")) MAX_LEAF = (uint32_t)std::min(4, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("TRR_BVH_ALWAYS_LEAF")) ALWAYS_LEAF = (uint32_t)std::min(4, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("TRR_BVH_LEAF_BIAS")) LEAF_BIAS = (float)std::atof(e);
+    if (const char* e = std::getenv("TRR_BVH_BINS")) NBINS = std::min(MAX_BINS, std::max(4, std::atoi(e)));
+    if (const char* e = std::getenv("TRR_BVH_SWEEP")) SWEEP_MAX = (uint32_t)std::max(0, std::atoi(e));
     if (ALWAYS_LEAF > MAX_LEAF) ALWAYS_LEAF = MAX_LEAF;
     if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
     n_threads = std::min(n_threads, 64u);

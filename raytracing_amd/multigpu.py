@@ -88,14 +88,23 @@ class ShardedRenderer:
     of all frames are issued on ONE stream, in frame order, so every rank issues its collectives in the same order."""
 
     def __init__(self, raytracer, rank: int = 0, world: int = 1, group=None, use_dist: bool = None,
-                 frames_in_flight: int = 2):
+                 frames_in_flight: int = 2, transport: str = None):
+        """``transport``: "device" = the strips are gathered GPU to GPU by the process group (nccl = RCCL over xGMI),
+        "host" = every rank copies its strip to host memory and the group gathers host buffers (gloo; render() then waits
+        for the frame).  Default: by the group's backend."""
         import torch
+        import torch.distributed as dist
 
         self.rt = raytracer
         self.rank, self.world, self.group = int(rank), int(world), group
         self.use_dist = (self.world > 1) if use_dist is None else bool(use_dist)
         if self.world > 1 and not self.use_dist:
             raise ValueError("world > 1 needs the process group (use_dist): the root assembles the strips of every rank")
+        if transport is None:
+            transport = "host" if (self.use_dist and dist.is_initialized() and dist.get_backend(group) == "gloo") else "device"
+        if transport not in ("device", "host"):
+            raise ValueError("transport must be 'device' or 'host'")
+        self.transport = transport
         self.device = torch.device("cuda", raytracer.ctx.device)
         self.sb = raytracer.strip_bytes(self.world)
         self.is_root = self.rank == 0
@@ -133,7 +142,16 @@ class ShardedRenderer:
         cs.wait_event(sl["rendered"])
         frame = None
         with torch.cuda.stream(cs):
-            if self.use_dist:
+            if self.use_dist and self.transport == "host":
+                # host buffers through the group (gloo has no device gather); same strips, same assemble
+                sl["rendered"].synchronize()
+                host = sl["strip"].cpu()
+                outs = [torch.empty_like(host) for _ in range(self.world)] if self.is_root else None
+                dist.gather(host, outs, dst=0, group=self.group)
+                if self.is_root:
+                    sl["strips"].copy_(torch.stack(outs), non_blocking=False)
+                src = sl["strips"] if self.is_root else None
+            elif self.use_dist:
                 # the single exchange of the path: finished RGB8 strips to the root (RCCL over xGMI with backend nccl)
                 dist.gather(sl["strip"], sl["views"] if self.is_root else None, dst=0, group=self.group)
                 src = sl["strips"] if self.is_root else None
