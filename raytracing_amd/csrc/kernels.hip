@@ -175,7 +175,7 @@ constexpr uint8_t NLEV_PENDING = 0xFF;   // nlev value of a camera sample whose 
 constexpr int STACK_LDS = TRR_STACK_LDS;       // per-lane (ref, tmin) entries kept in LDS
 constexpr int STACK_SPILL = TRACE_STACK_ENTRIES - STACK_LDS;     // further entries in a per-thread HBM spill area (rarely touched)
 #ifndef TRR_REFILL_MIN
-#define TRR_REFILL_MIN 36
+#define TRR_REFILL_MIN 42   // swept 24..48 with TRR_DEFER_END: 31.4 / 30.9 / 30.6 (36) / 30.25 (42) / 30.5 ms
 #endif
 constexpr int REFILL_MIN = TRR_REFILL_MIN;      // re-fill when at least this many of the 64 lanes are idle
 #ifndef TRR_PRUNE_REL
@@ -188,6 +188,9 @@ constexpr float PRUNE_REL = TRR_PRUNE_REL;
 constexpr int NODE_BIAS = TRR_NODE_BIAS;
 #ifndef TRR_TRIS_PER_STEP
 #define TRR_TRIS_PER_STEP 2   // 2: -4 % frame time against 1 (fewer, fatter leaf iterations); whole leaves cost a wave of occupancy
+#endif
+#ifndef TRR_DEFER_END
+#define TRR_DEFER_END 1   // end-of-ray transitions wait for company: 22.0 M -> 9.4 M executions of the block per 4K frame, -2.2 %
 #endif
 #ifndef TRR_CHUNK_DIV
 #define TRR_CHUNK_DIV 8
@@ -361,12 +364,37 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
         }
 
         // ---- transition: object finished / raycast finished / ray finished ----------------------
+#if !TRR_DEFER_END
         if (COUNT) {
             unsigned long long tm = __ballot(cur == REF_EMPTY);
             if (tm != 0ull && lane == (uint32_t)__ffsll((long long)tm) - 1u) c_wtrans++;
             if (cur == REF_EMPTY) c_ltrans++;
         }
+#endif
+#if TRR_DEFER_END
+        // The transition block is long (winner re-evaluation, object-space ray, divisions) and costs a wavefront the same
+        // whether 1 or 64 lanes need it.  Lanes that only have to END their ray (last object done) can wait: they would
+        // sit idle until the next re-fill anyway.  The block runs when a lane needs it to go on (fresh ray, next object),
+        // when the waiting + idle lanes reach the re-fill threshold, or when no lane has traversal work left.
+        bool run_trans;
+        {
+            const bool is_empty = cur == REF_EMPTY;
+            const bool can_wait = is_empty && obj_i != 0xFFFFFFFFu && obj_i + 1u >= fp.n_objs;
+            const unsigned long long m_empty = __ballot(is_empty);
+            const unsigned long long m_wait = __ballot(can_wait);
+            const unsigned long long m_work = __ballot(cur < REF_IDLE);
+            run_trans = m_empty != m_wait || m_work == 0ull ||
+                        __popcll(m_wait) + __popcll(__ballot(cur == REF_IDLE)) >= REFILL_MIN;
+        }
+        if (COUNT && run_trans) {
+            unsigned long long tm = __ballot(cur == REF_EMPTY);
+            if (tm != 0ull && lane == (uint32_t)__ffsll((long long)tm) - 1u) c_wtrans++;
+            if (cur == REF_EMPTY) c_ltrans++;
+        }
+        if (run_trans && cur == REF_EMPTY) {
+#else
         if (cur == REF_EMPTY) {
+#endif
             // object.rs:206-219: best candidate of the object -> world space, then mod.rs:50 ranks objects by
             // |point_world - ray.origin| (first object wins ties: strict <, NaN greatest)
             // (a shadow ray only reports the occluder's material: with a single object there is nothing to rank, so the
