@@ -80,7 +80,8 @@ static_assert(sizeof(RayRec) == 32, "RayRec must be 32 bytes");
 
 // Closest-hit result of a chain (camera / reflection) ray, indexed by queue position.
 struct alignas(16) HitRec {
-    float u, v, w;      // barycentric weights of (a, b, c)
+    float ox, oy, oz;   // origin of the raycast that found the hit (advances during the transparency march, mod.rs:106);
+                        // k_setup re-evaluates the barycentric weights from it, the chain ray's direction and the slot
     uint32_t slot;      // TriRec index, 0xFFFFFFFF = miss
     uint32_t obj;
     uint32_t tri;       // triangle id (row in the object's triangle array) of the LAST hit of the march

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
     uint32_t r_out = 0, r_sample = 0, r_meta = 0;
     // one raycast (all objects)
     uint32_t obj_i = 0;
-    float g_key = 0, g_u = 0, g_v = 0, g_w = 0, t_lim = INFINITY;
+    float g_key = 0, t_lim = INFINITY;
     uint32_t g_slot = 0, g_obj = 0;
     // one object
     F3 oo = f3(0, 0, 0), od = f3(0, 0, 0), oi = f3(0, 0, 0);
@@ -397,12 +397,15 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
 #endif
             // object.rs:206-219: best candidate of the object -> world space, then mod.rs:50 ranks objects by
             // |point_world - ray.origin| (first object wins ties: strict <, NaN greatest)
-            // (a shadow ray only reports the occluder's material: with a single object there is nothing to rank, so the
-            // winner of the object is the winner of the raycast and its barycentrics are never read)
-            const bool rank_free = !RAYGEN && fp.n_objs == 1u && (r_meta & 0x100u) != 0u;
+            // With a single object there is nothing to rank: the winner of the object is the winner of the raycast.  Its
+            // barycentrics are not needed here either: a shadow ray only reports the occluder's material, and k_setup
+            // re-evaluates a chain ray's winner from (slot, ray) with full wavefronts -- the same tri_test on the same
+            // inputs, so the same bits -- instead of the few lanes that end their object in this iteration.
+            const bool rank_free = fp.n_objs == 1u;
             if ((fl & F_OHAVE) && rank_free) {
                 fl = (fl | F_GHAVE) & ~F_OHAVE;
                 g_slot = o_slot;
+                g_obj = 0u;
             }
             if (fl & F_OHAVE) {
                 const ObjRec* ob = fp.objs + obj_i;
@@ -420,7 +423,6 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 else better = key < g_key;
                 if (better) {
                     fl |= F_GHAVE; g_key = key; g_slot = o_slot; g_obj = obj_i;
-                    g_u = h.u; g_v = h.v; g_w = h.w;
                     // later objects only need boxes nearer than this hit (ray parameter + slack)
                     float th = sqrtf(h.key) / len_d;
                     if (th == th) t_lim = th * (1.0f + PRUNE_REL);
@@ -444,7 +446,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                         io.occ[((size_t)level * fp.n_lights + light) * bp.cap + r_sample] = mat >= 0 ? mat : -2;
                     } else {
                         float4* dst = reinterpret_cast<float4*>(io.hits + r_out);
-                        dst[0] = make_float4(g_u, g_v, g_w, __uint_as_float(g_slot));
+                        dst[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(g_slot));   // the origin THIS raycast used (march)
                         dst[1] = make_float4(__uint_as_float(g_obj), __uint_as_float(tri_id), 0.0f, 0.0f);
                         if (RAYGEN && first_cast) io.nlev[r_meta] = NLEV_PENDING;   // k_setup shades it at level 0
                     }
@@ -720,11 +722,16 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
                 io.nlev[sample] = (uint8_t)lvl;
             } else {
                 hit = true;
-                float u = h0.x, v = h0.y, w = h0.z;
                 const ObjRec* ob = fp.objs + __float_as_uint(h1.x);
                 const float4* tp = reinterpret_cast<const float4*>(fp.tris + slot);
                 float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
                 F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x);
+                // the winner's barycentrics (triangle.rs:84): the trace kernel kept only the slot and the origin its
+                // last raycast used; object-space ray and exact test are the ones of k_trace (object.rs:186-189)
+                TriHit th;
+                th.u = th.v = th.w = 0.0f; th.point = f3(0, 0, 0); th.key = 0.0f;
+                (void)tri_test(q0, q1, q2, q3.z, xform_point(ob->inv, f3(h0.x, h0.y, h0.z)), xform_vec(ob->inv, D), fp.delta, th);
+                const float u = th.u, v = th.v, w = th.w;
                 const InterpRec* ip = fp.interp + ob->tri_base + __float_as_uint(q3.x);
                 const float4* ipp = reinterpret_cast<const float4*>(ip);
                 float4 i0 = ipp[0], i1 = ipp[1], i2 = ipp[2], i3 = ipp[3];
