@@ -517,6 +517,14 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 const float4* nd = reinterpret_cast<const float4*>(fp.nodes + cur);
                 float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
                 uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
+#ifdef TRR_DUMMY_VALU
+                {   // experiment: TRR_DUMMY_VALU extra dependent vector instructions per node step (is the kernel VALU-bound?)
+                    float dv = lox.x;
+#pragma unroll
+                    for (int k = 0; k < TRR_DUMMY_VALU; ++k) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dv));
+                    asm volatile("" ::"v"(dv));
+                }
+#endif
                 if (COUNT) {
                     c_nodes++; c_boxes += 4;
                     if (lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) c_wnode++;
