@@ -70,3 +70,21 @@ def test_cpp_cli_renders_the_same_frame(scene_dir, tmp_path):
     finally:
         rt.close()
     assert np.array_equal(load_image_rgb8(png), want)
+
+
+def test_cpp_cli_device_build_renders_the_same_frame(scene_dir, tmp_path):
+    """--build device: the tree is built on the GPU (TRR_BUILD_DEVICE); same bytes as the host-built render."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "trr_cli")
+    out = {}
+    for build in ("host", "device"):
+        png = os.path.join(str(tmp_path), build + ".png")
+        p = subprocess.run([exe, scene_dir, "-o", png, "--max-depth", "4", "--build", build, "--stats"], capture_output=True, text=True,
+                           timeout=100)
+        assert p.returncode == 0, p.stdout + p.stderr
+        info = json.loads(p.stdout.strip().splitlines()[-1])
+        assert info["build"] == build and info["bvh_nodes"] >= 1 and info["bvh_depth"] >= 1
+        out[build] = load_image_rgb8(png)
+    assert np.array_equal(out["host"], out["device"])
+    p = subprocess.run([exe, scene_dir, "--build", "gpu"], capture_output=True, text=True, timeout=100)
+    assert p.returncode == 2 and "host or device" in p.stderr
