@@ -48,6 +48,25 @@ def test_create_without_gpu_fails_loudly_not_silently():
         N.check(rc)
 
 
+def test_null_handles_are_rejected_before_any_device_call():
+    """Every entry point returns a status instead of aborting (include/trayracer_hip.h, rules of the boundary); with NULL
+    handles that happens before the first HIP call, so it can be checked without a GPU."""
+    L = N.lib()
+    h = C.c_void_p()
+    assert L.trr_scene_create(None, None, 0, None, 0, C.byref(h)) == N.TRR_ERR_INVALID and not h
+    assert L.trr_scene_create_ex(None, None, 0, None, 0, N.TRR_BUILD_DEVICE, C.byref(h)) == N.TRR_ERR_INVALID and not h
+    assert L.trr_scene_get_info(None, None) == N.TRR_ERR_INVALID
+    assert L.trr_scene_validate(None) == N.TRR_ERR_INVALID
+    assert L.trr_scene_set_lights(None, None, 0) == N.TRR_ERR_INVALID
+    assert L.trr_render(None, None, 1e-5, 5, 0, None, None, None, None, None, None, None) == N.TRR_ERR_INVALID
+    assert L.trr_render_blocks(None, None, 1e-5, 5, 0, 0, None, None, None, None, None) == N.TRR_ERR_INVALID
+    assert L.trr_render_shard_device(None, None, 1e-5, 5, 0, 0, 1, None, 0, None, None, None, None, None) == N.TRR_ERR_INVALID
+    assert L.trr_collect_stats(None) == N.TRR_ERR_INVALID
+    assert b"NULL" in L.trr_last_error(None)
+    L.trr_scene_destroy(None)
+    L.trr_destroy(None)
+
+
 def test_version_string():
     assert b"gfx950" in N.lib().trr_version()
 
