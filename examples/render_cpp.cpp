@@ -133,10 +133,17 @@ int main(int argc, char** argv) {
         r.render(sc);
         uint16_t last = 0;
         int polls = 0;
+        size_t painted_last = 0;
         while (!r.finished()) {
             uint16_t p = r.progress.load();
             if (p < last) { std::fprintf(stderr, "progress went backwards\n"); return 1; }
             last = p;
+            // the image fills block by block (render.rs:170-183): a snapshot never loses painted pixels
+            Image snap = r.snapshot();
+            size_t painted = 0;
+            for (uint8_t v : snap.rgb) painted += v != 0;
+            if (painted < painted_last) { std::fprintf(stderr, "painted pixels went backwards\n"); return 1; }
+            painted_last = painted;
             ++polls;
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
         }

@@ -29,6 +29,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -362,20 +363,29 @@ public:
     std::atomic<uint16_t> progress{0};
     std::atomic<int32_t> cancel{0};
     std::optional<std::thread> thread;
-    Image image;
+    Image image;               // Arc<Mutex<RgbImage>> in the reference: hold image_mutex (or use snapshot()) while a render runs
+    std::mutex image_mutex;
     std::atomic<uint32_t> time{0};
     std::string error;   // the reference's render thread has no error channel; this one keeps the message
 
     bool finished() const { return progress.load() == UINT16_MAX; }
+    // a copy of the (possibly partial) frame, safe while the render thread is painting blocks into `image`
+    Image snapshot() {
+        std::lock_guard<std::mutex> lock(image_mutex);
+        return image;
+    }
 
     // Render::render (render.rs:39-71): resets the handle and spawns the render thread on a copy of the scene
     // image fills block by block while the thread runs (the reference's sink paints every finished block into it,
     // render.rs:170-183); blocks_per_batch = blocks that appear together (0 = one row of blocks)
     void render(Scene scene, float delta = 1e-5f, uint32_t max_depth = 5, uint32_t blocks_per_batch = 0) {
         if (thread) throw std::logic_error("a render is already in flight (ui/statusbar.rs:142-157 disables the button)");
-        image.width = scene.camera.resolution.first;
-        image.height = scene.camera.resolution.second;
-        image.rgb.assign((size_t)image.width * image.height * 3, 0);   // render.rs:51
+        {
+            std::lock_guard<std::mutex> lock(image_mutex);
+            image.width = scene.camera.resolution.first;
+            image.height = scene.camera.resolution.second;
+            image.rgb.assign((size_t)image.width * image.height * 3, 0);   // render.rs:51
+        }
         progress = 0;                                                  // render.rs:54
         time = 0;                                                      // render.rs:55
         error.clear();
@@ -387,6 +397,7 @@ public:
                     progress = (uint16_t)std::lround(65535.0 * done / std::max(1u, total));
                 };
                 Raytracer::BlockSink sink = [this](uint32_t xb, uint32_t yb, uint32_t bw, uint32_t bh, const uint8_t* rgb) {
+                    std::lock_guard<std::mutex> lock(image_mutex);     // `let mut image = self.image.lock()`, render.rs:170
                     for (uint32_t y = 0; y < bh; ++y)                  // render.rs:170-183
                         std::memcpy(&image.rgb[((size_t)(yb * bh + y) * image.width + (size_t)xb * bw) * 3], rgb + (size_t)y * bw * 3, (size_t)bw * 3);
                 };
