@@ -517,6 +517,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
                 const float4* nd = reinterpret_cast<const float4*>(fp.nodes + cur);
                 float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
                 uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
+#ifdef TRR_DUMMY_LOAD
+                {   // experiment: one more 16-B load per lane from the node's own cache line (is the L1 / address pipe a limit?)
+                    float4 extra = nd[7];
+                    asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
+                }
+#endif
 #ifdef TRR_DUMMY_VALU
                 {   // experiment: TRR_DUMMY_VALU extra dependent vector instructions per node step (is the kernel VALU-bound?)
                     float dv = lox.x;
