@@ -828,6 +828,7 @@ static void finish_stats(trr_ctx* ctx, const trr_ctx::PendingStats& f) {
         stats->node_visits += k[0]; stats->box_tests += k[1]; stats->tri_tests += k[2]; stats->rays_march += k[3];
         stats->wave_node_steps += k[4]; stats->wave_tri_steps += k[5]; stats->wave_outer_steps += k[6]; stats->wave_lane_steps += k[7];
         stats->wave_trans_steps += k[8]; stats->trans_lanes += k[9];
+        stats->wave_uniform_node_steps += k[10];
     }
     float span = 0.0f;
     for (size_t i = 0; i + 1 < f.ev_count; i += 2) {

@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
     uint32_t cur = REF_IDLE;
     int sp = 0;
     unsigned long long c_nodes = 0, c_boxes = 0, c_tris = 0, c_march = 0;
-    unsigned long long c_wnode = 0, c_wtri = 0, c_wouter = 0, c_lanes = 0, c_wtrans = 0, c_ltrans = 0;   // wave-level step counts (SIMD efficiency)
+    unsigned long long c_wnode = 0, c_wtri = 0, c_wouter = 0, c_lanes = 0, c_wtrans = 0, c_ltrans = 0, c_wuni = 0;   // wave-level step counts (SIMD efficiency)
 
     auto push = [&](uint32_t ref, float tmin) {
         uint2 e = make_uint2(ref, __float_as_uint(tmin));
@@ -533,7 +533,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
 #endif
                 if (COUNT) {
                     c_nodes++; c_boxes += 4;
-                    if (lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) c_wnode++;
+                    const unsigned long long am = __ballot(true);
+                    const uint32_t first_lane = (uint32_t)__ffsll((long long)am) - 1u;
+                    if (lane == first_lane) c_wnode++;
+                    // node steps in which every participating lane stands on the SAME node
+                    const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                    if (__ballot(cur == cur0) == am && lane == first_lane) c_wuni++;
                 }
                 // [crate] Ray::intersects_aabb per child, same arithmetic as the per-triangle test below, so a parent
                 // box (exact union of its children) can never reject what a triangle's own box accepts.  Written with
@@ -656,6 +661,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
             c_lanes += __shfl_down(c_lanes, off);
             c_wtrans += __shfl_down(c_wtrans, off);
             c_ltrans += __shfl_down(c_ltrans, off);
+            c_wuni += __shfl_down(c_wuni, off);
         }
         if (lane == 0) {
             atomicAdd(io.counters + 0, c_nodes);
@@ -668,6 +674,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
             atomicAdd(io.counters + 7, c_lanes);
             atomicAdd(io.counters + 8, c_wtrans);
             atomicAdd(io.counters + 9, c_ltrans);
+            atomicAdd(io.counters + 10, c_wuni);
         }
     }
 }

@@ -24,5 +24,6 @@ print(os.path.basename(sys.argv[1]), "frame ms min %.2f med %.2f" % (min(ts), so
       "wave steps node %.1fM tri %.1fM outer %.1fM lane-steps %.0fM node-util %.2f tri-util %.2f" % (
           st.wave_node_steps / 1e6, st.wave_tri_steps / 1e6, st.wave_outer_steps / 1e6, st.wave_lane_steps / 1e6,
           st.node_visits / 64 / max(1, st.wave_node_steps), st.box_tests / 64 / max(1, st.wave_tri_steps)),
-      "trans wave-steps %.1fM lanes/step %.1f" % (st.wave_trans_steps / 1e6, st.trans_lanes / max(1, st.wave_trans_steps)), flush=True)
+      "trans wave-steps %.1fM lanes/step %.1f" % (st.wave_trans_steps / 1e6, st.trans_lanes / max(1, st.wave_trans_steps)),
+      "uniform node steps %.1fM (%.0f %%)" % (st.wave_uniform_node_steps / 1e6, 100.0 * st.wave_uniform_node_steps / max(1, st.wave_node_steps)), flush=True)
 rt.close()
