@@ -192,6 +192,24 @@ def test_transparency_march(ctx, oracle_mod):
     assert out["stats"].rays_march > 0
 
 
+def test_transparency_march_in_a_single_object(ctx, oracle_mod):
+    """The same pane and wall as ONE object with two materials and a mirror floor: with one object the trace kernel
+    keeps only the winner's slot and the origin of the raycast that found it (which the march advances, mod.rs:106);
+    k_setup must rebuild the barycentrics from exactly that origin."""
+    rows = tri_rows(((-5, -5, -1.0), (5, -5, -1.0), (5, 5, -1.0)), ((-5, -5, -1.0), (5, 5, -1.0), (-5, 5, -1.0)),
+                    ((-5, -5, -1.3), (5, -5, -1.3), (5, 5, -1.3)), ((-5, -5, -1.3), (5, 5, -1.3), (-5, 5, -1.3)),
+                    ((-5, -0.4, 0.0), (5, -0.4, 0.0), (5, -0.4, -1.3)), ((-5, -0.4, 0.0), (5, -0.4, -1.3), (-5, -0.4, -1.3)))
+    mats = [mat(kd=(1, 0, 0), illum=6, dissolve=0.5), mat(kd=(0, 1, 0), illum=0, dissolve=0.0), mat(kd=(0.5, 0.5, 0.9), illum=3, dissolve=0.0)]
+    obj = Object(triangles=rows, material_index=np.array([0, 0, 1, 1, 2, 2], np.int32), materials=mats)
+    sc = Scene(objects=[obj], lights=[Light(np.array([0, 0, 0.5], F32), np.array([1, 1, 1], F32), 2.0),
+                                      Light(np.array([1, 1, -0.5], F32), np.array([1, 0.8, 0.6], F32), 1.0)],
+               camera=front_camera(64, 48), settings=Settings())
+    out = gpu_render(ctx, sc, counters=True, max_depth=4)
+    ref = oracle_mod.OracleScene(sc).render(shade=oracle_mod.SHADE_HOISTED, max_depth=4)
+    assert_parity(out, ref, what="transparency march, one object")
+    assert out["stats"].rays_march > 0 and out["stats"].rays_reflection > 0
+
+
 def test_update_camera_lights_instances_between_renders(ctx, oracle_mod):
     sc = standin.parity_scene(96, 72, detail=6)
     rt = Raytracer(sc, max_depth=3, context=ctx)
