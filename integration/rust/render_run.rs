@@ -1,46 +1,37 @@
-// UNVERIFIED (no Rust toolchain in the build image).  Body of RenderingThread::run (src/raytracer/render.rs:95-193) with
-// the rayon block loop (render.rs:105-152) replaced by the HIP backend; the sink (render.rs:155-186) is unchanged in
-// what it does.  Falls back to the existing rayon path when no HIP device can be opened.
-fn run(self) {
-    let start = Instant::now();
-    let (width, height) = self.image.lock().dimensions();
-
-    let rendered = (|| -> anyhow::Result<()> {
-        let gpu = hip::Backend::new(0)?;                                   // once per process in a real integration
-        let scene = gpu.upload(&self.scene, hip::BUILD_HOST)?;             // replaces Raytracer::new(self.scene, 1e-5, 5)
-        let texture = &self.texture;
-        let image = &self.image;
-        let ctx = &self.ctx;
-        let progress = &self.progress;
-        let mut on_block = |rgb: &[u8], x_block: u32, y_block: u32, bw: u32, bh: u32| {
-            let pixels = rgb.chunks_exact(3).map(|p| Color32::from_rgb(p[0], p[1], p[2])).collect::<Vec<_>>();
-            texture.clone().set_partial(
-                [(x_block * bw) as usize, (y_block * bh) as usize],
-                ImageData::Color(Arc::new(ColorImage { size: [bw as usize, bh as usize], pixels })),
-                TextureOptions::default(),
-            );
-            let mut image = image.lock();
-            for y in 0..bh {
-                for x in 0..bw {
-                    let i = ((x + y * bw) * 3) as usize;
-                    image.put_pixel(x_block * bw + x, y_block * bh + y, image::Rgb([rgb[i], rgb[i + 1], rgb[i + 2]]));
-                }
-            }
-            ctx.request_repaint();
-        };
-        let mut on_progress = |done: u32, total: u32| {                     // render.rs:143-149
-            progress.store((done as f32 / total as f32 * f32::from(u16::MAX)).round() as u16, Ordering::Relaxed);
-        };
-        scene.render_blocks(1e-5, 5, &self.cancel, &mut on_block, &mut on_progress)?;
-        Ok(())
-    })();
-    if let Err(e) = rendered {
-        warn!("HIP backend unavailable ({e}); rendering on the CPU");
-        // ... the existing rayon block loop of render.rs:103-186 ...
-    }
-    debug_assert!(width >= 20 && height >= 20);                            // the backend returns an error below 20 px
-
-    self.progress.store(u16::MAX, Ordering::Relaxed);                       // render.rs:188
-    self.time.store(start.elapsed().as_millis() as u32, Ordering::Relaxed); // render.rs:189-190
-    info!("rendering finished: {:?}", start.elapsed());
+// UNVERIFIED (no Rust toolchain in the build image).  What changes in RenderingThread::run
+// (src/raytracer/render.rs:95-193): the rayon pipeline that PRODUCES blocks (render.rs:105-152, from `Raytracer::new` to the
+// closure returning `(pixels, x_block, y_block)`) is replaced by the call below; the code that CONSUMES a block -- the body
+// of the `for_each_with` closure, render.rs:155-186, which paints the texture and the image and requests a repaint --
+// is kept and becomes the local closure `paint` (not repeated here).
+//
+//     let paint = |pixels: Vec<Color32>, x_block: u32, y_block: u32| { /* render.rs:156-185, unchanged */ };
+#[cfg(trayracer_hip)]
+fn render_on_gpu(
+    scene: &Scene,
+    cancel: &AtomicBool,
+    progress: &AtomicU16,
+    mut paint: impl FnMut(Vec<Color32>, u32, u32),
+) -> anyhow::Result<bool> {
+    let gpu = hip::Backend::new(0)?;                    // one per process in a real integration (a `OnceLock`)
+    let on_gpu = gpu.upload(scene, hip::BUILD_HOST)?;    // stands in for Raytracer::new(scene, 1e-5, 5), render.rs:105
+    let mut on_block = |rgb: &[u8], x_block: u32, y_block: u32, _w: u32, _h: u32| {
+        paint(rgb.chunks_exact(3).map(|p| Color32::from_rgb(p[0], p[1], p[2])).collect(), x_block, y_block);
+    };
+    let mut on_progress = |done: u32, total: u32| {     // same scale as render.rs:143-149
+        let part = done as f32 / total.max(1) as f32;
+        progress.store((part * f32::from(u16::MAX)).round() as u16, Ordering::Relaxed);
+    };
+    on_gpu.render_blocks(1e-5, 5, cancel, &mut on_block, &mut on_progress)
 }
+
+// In `run`, where the rayon pipeline stood:
+//
+//     #[cfg(trayracer_hip)]
+//     let done = render_on_gpu(&self.scene, &self.cancel, &self.progress, &mut paint)
+//         .map_err(|e| warn!("HIP backend: {e}"))
+//         .is_ok();
+//     #[cfg(not(trayracer_hip))]
+//     let done = false;
+//     if !done { /* the existing rayon pipeline, feeding `paint` */ }
+//
+// The lines after it (progress = u16::MAX, time, the log line: render.rs:188-192) stay as they are.
