@@ -308,7 +308,19 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
         return REF_EMPTY;
     };
 
+#ifdef TRR_PAD_VGPRS
+    // experiment: TRR_PAD_VGPRS registers kept live through the loop without a single instruction.  The register count
+    // matters even below 128 (the grid's four blocks per CU are resident either way): +8 registers +5.6 % frame time,
+    // +19 +10.8 % -- the blocks of the OTHER work set's launches share the CU only while registers are left.
+    float pad_regs[TRR_PAD_VGPRS];
+#pragma unroll
+    for (int k = 0; k < TRR_PAD_VGPRS; ++k) pad_regs[k] = (float)(tid + k);
+#endif
     for (;;) {
+#ifdef TRR_PAD_VGPRS
+#pragma unroll
+        for (int k = 0; k < TRR_PAD_VGPRS; ++k) asm volatile("" : "+v"(pad_regs[k]));
+#endif
         // ---- re-fill idle lanes -------------------------------------------------------------
         unsigned long long idle = __ballot(cur == REF_IDLE);
         if (idle != 0ull && !exhausted) {
@@ -648,6 +660,10 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
         }
     }
 
+#ifdef TRR_PAD_VGPRS
+#pragma unroll
+    for (int k = 0; k < TRR_PAD_VGPRS; ++k) asm volatile("" ::"v"(pad_regs[k]));
+#endif
     if (COUNT) {
         // wave reduction, then one atomic per wavefront and counter
         for (int off = 32; off > 0; off >>= 1) {
