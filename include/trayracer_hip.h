@@ -220,6 +220,22 @@ int trr_render_shard_device(trr_ctx* ctx, trr_scene* scene, float delta, uint32_
                             const volatile int32_t* cancel_flag, trr_progress_cb progress, void* user,
                             trr_stats* stats_out);
 size_t trr_strip_bytes(uint32_t width, uint32_t height, uint32_t n_shards);
+
+/* The entry point that allocates nothing.  It has NO counterpart in the reference; it exists for callers that cannot call
+ * hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same arguments, strip
+ * layout and bytes as trr_render_shard_device without its statistics / cancel / progress parameters, but every work
+ * buffer (ray queues, hit and shaded-hit records, occluder codes, traversal-stack spill, queue counters) lives in ONE
+ * file-scope `static __device__` array of trr_noalloc_scratch_bytes() = 256 MiB that each GPU the library runs on holds
+ * until the process ends; the call makes no hipMalloc / hipFree / hipHostMalloc / event creation, only memsets and
+ * kernel launches on `stream` (NULL = the context's stream), one batch of whole blocks after the other.
+ * Limit: the work set of ONE block (block_w*block_h*samples samples; the bytes per sample grow with lights x max_depth)
+ * must fit the array, else TRR_ERR_INVALID with the figures in trr_last_error() -- e.g. a 1080p block at 16 spp, 4 lights,
+ * max_depth 5 fits (about 4 blocks per batch); a 4K block at 16 spp does not.  Every call on a GPU shares that GPU's
+ * array: calls that overlap on one GPU (two streams, two threads, two contexts of one device) race; calls queued on one
+ * stream are ordered by it. */
+int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t shard,
+                                    uint32_t n_shards, void* strip_dev, size_t strip_bytes, void* stream);
+size_t trr_noalloc_scratch_bytes(void);
 /* De-interleaves n_shards gathered strips (contiguous, trr_strip_bytes each) into the row-major RGB8 frame
  * (width*height*3 device bytes; unrendered remainder pixels are zeroed). */
 int trr_assemble_device(trr_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_shards,

@@ -90,7 +90,7 @@ EXPORTS = [
     "trr_create", "trr_destroy", "trr_last_error", "trr_scene_create", "trr_scene_create_ex", "trr_scene_get_info",
     "trr_scene_validate", "trr_scene_destroy", "trr_scene_set_instances",
     "trr_scene_set_lights", "trr_scene_set_settings", "trr_scene_set_camera", "trr_render", "trr_render_blocks", "trr_render_shard_device",
-    "trr_strip_bytes", "trr_assemble_device", "trr_synchronize", "trr_collect_stats", "trr_object_matrices", "trr_camera_ray", "trr_version",
+    "trr_strip_bytes", "trr_render_shard_device_noalloc", "trr_noalloc_scratch_bytes", "trr_assemble_device", "trr_synchronize", "trr_collect_stats", "trr_object_matrices", "trr_camera_ray", "trr_version",
 ]
 
 
@@ -153,6 +153,10 @@ def lib() -> C.CDLL:
     L.trr_render_blocks.argtypes = [vp, vp, f32, u32, u32, u32, vp, vp, vp, vp, vp]
     L.trr_render_shard_device.restype = i32
     L.trr_render_shard_device.argtypes = [vp, vp, f32, u32, u32, u32, u32, vp, C.c_size_t, vp, vp, vp, vp, vp]
+    L.trr_render_shard_device_noalloc.restype = i32
+    L.trr_render_shard_device_noalloc.argtypes = [vp, vp, f32, u32, u32, u32, vp, C.c_size_t, vp]
+    L.trr_noalloc_scratch_bytes.restype = C.c_size_t
+    L.trr_noalloc_scratch_bytes.argtypes = []
     L.trr_strip_bytes.restype = C.c_size_t
     L.trr_strip_bytes.argtypes = [u32, u32, u32]
     L.trr_assemble_device.restype = i32

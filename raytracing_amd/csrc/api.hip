@@ -43,6 +43,13 @@ thread_local std::string g_tls_error;
 
 using namespace trr;
 
+// ---- the no-allocation entry point's work memory (trr_render_shard_device_noalloc) ---------------------------------------
+// One file-scope device array per GPU the library runs on, held until the process ends.  `scratch` is a host-side stand-in
+// here, NOT a device address: trr_create asks hipGetSymbolAddress for the array's address on its device (every GPU holds
+// its own copy at its own address) and everything below uses that pointer (ctx->scratch), never the name.
+static constexpr size_t SCRATCH_BYTES = 256ull << 20;   // 256 MiB of the 288 GB
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
 // ---- opaque handles --------------------------------------------------------------------------------------
 struct DevBuf {
     void* p = nullptr;
@@ -69,6 +76,7 @@ struct trr_ctx {
     DevBuf strip, frame, ids_obj, ids_tri;
     std::vector<hipEvent_t> events;
     int bpc[2][2] = {{0, 0}, {0, 0}};    // resident 256-thread blocks per CU of k_trace<RAYGEN, COUNT> (occupancy query, once)
+    unsigned char* scratch = nullptr;    // this device's copy of the static `scratch` array (hipGetSymbolAddress in trr_create)
     uint32_t rotate = 0;                 // round-robin start lane of single-batch frames
     uint64_t budget_total = 0;           // bytes the work sets of all lanes may take together (set at the first render)
     size_t events_used = 0;              // events handed to frames whose statistics are still pending
@@ -170,7 +178,11 @@ int trr_create(int device_id, trr_ctx** out) {
     if (device_id < 0 || device_id >= n) return fail(nullptr, TRR_ERR_INVALID, "trr_create: device_id out of range");
     trr_ctx* ctx = new trr_ctx();
     ctx->device = device_id;
-    HIPCHK(ctx, hipSetDevice(device_id));
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, TRR_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    }
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, device_id);
     if (e != hipSuccess) {
@@ -195,6 +207,15 @@ int trr_create(int device_id, trr_ctx** out) {
         trr_destroy(ctx);
         return fail(nullptr, TRR_ERR_DEVICE, "hipEventCreate failed");
     }
+    // this device's copy of the static scratch array, once per context (= per device), with the device current
+    e = hipGetSymbolAddress((void**)&ctx->scratch, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || ctx->scratch == nullptr) {
+        trr_destroy(ctx);
+        return fail(nullptr, TRR_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    }
+    // resident 256-thread blocks per CU of the four k_trace instantiations (each has its own register count)
+    for (int rg = 0; rg < 2; ++rg)
+        for (int cn = 0; cn < 2; ++cn) ctx->bpc[rg][cn] = std::max(1, std::min(trace_blocks_per_cu(rg != 0, cn != 0), 8));
     *out = ctx;
     return TRR_OK;
 }
@@ -780,6 +801,40 @@ size_t trr_strip_bytes(uint32_t width, uint32_t height, uint32_t n_shards) {
     return (size_t)max_owned_blocks(t, n_shards) * t.bw * t.bh * 3;
 }
 
+// Everything the kernels need about the frame, from the scene's current camera / settings / lights.
+static FrameParams frame_params_of(const trr_scene* sc, const Tiling& tl, uint32_t shard, uint32_t n_shards, float delta,
+                                   uint32_t max_depth) {
+    const bool aa = sc->settings.anti_aliasing != 0;
+    const uint32_t spp = aa ? sc->settings.samples : 1u;
+    const uint32_t L = sc->n_lights;
+    FrameParams fp{};
+    fp.nodes = (const Node4*)sc->nodes.p; fp.tris = (const TriRec*)sc->tris.p; fp.interp = (const InterpRec*)sc->interp.p;
+    fp.objs = (const ObjRec*)sc->objs.p; fp.mats = (const MatRec*)sc->mats.p; fp.texs = (const TexRec*)sc->texs.p;
+    fp.texels = (const uint8_t*)sc->texels.p; fp.lights = (const LightRec*)sc->lights.p;
+    fp.n_objs = sc->n_objs; fp.n_lights = L;
+    for (int k = 0; k < 3; ++k) {
+        fp.ambient[k] = sc->settings.ambient_color[k];
+        fp.sky_color[k] = sc->settings.skybox_color[k];
+        fp.cam_pos[k] = sc->camera.position[k];
+        fp.cam_x[k] = sc->cam_x[k]; fp.cam_y[k] = sc->cam_y[k]; fp.cam_z[k] = sc->cam_z[k];
+    }
+    fp.ambient_intensity = sc->settings.ambient_intensity;
+    fp.sky = sc->settings.skybox_is_image ? (const uint8_t*)sc->sky.p : nullptr;
+    fp.sky_w = sc->sky_w; fp.sky_h = sc->sky_h;
+    fp.aa = aa ? 1u : 0u;
+    fp.spp = spp;
+    {
+        float sq = std::sqrt((float)sc->settings.samples);   // mod.rs:226
+        fp.sqrt_spp = sq >= 4294967296.0f ? 0xFFFFFFFFu : (sq > 0.0f ? (uint32_t)sq : 0u);
+    }
+    fp.seed = sc->settings.seed;
+    fp.cam_focal = sc->cam_focal;
+    fp.width = tl.w; fp.height = tl.h; fp.bw = tl.bw; fp.bh = tl.bh; fp.nbx = tl.nbx; fp.nby = tl.nby;
+    fp.shard = shard; fp.n_shards = n_shards;
+    fp.delta = delta; fp.max_depth = max_depth;
+    return fp;
+}
+
 static hipEvent_t get_event(trr_ctx* ctx, size_t i) {
     while (ctx->events.size() <= i) {
         hipEvent_t ev;
@@ -842,6 +897,91 @@ static void finish_stats(trr_ctx* ctx, const trr_ctx::PendingStats& f) {
     stats->blocks_rendered = f.blocks_done;
     stats->ms_total = span;   // first kernel start to last kernel end of the frame, on the device clock
 }
+
+// Raw device pointers of one work set: the buffers of one batch in flight (hipMalloc'ed per context by the ordinary entry
+// points, carved out of the library's static scratch array by trr_render_shard_device_noalloc).
+struct WorkView {
+    HitRec* hits = nullptr;
+    float* level = nullptr;
+    float* term = nullptr;
+    uint8_t* nlev = nullptr;
+    int32_t* occ = nullptr;
+    RayRec* shadow_q = nullptr;
+    RayRec* chain_q[2] = {nullptr, nullptr};
+    void* counters = nullptr;   // RB_STRIDE bytes: queue counters + kernel counters
+    uint2* spill = nullptr;
+};
+
+// bytes of one work set for batches of `cap` samples (cap a multiple of 64), every buffer 256-B aligned
+struct WorkLayout {
+    size_t hits, level, term, nlev, occ, shadow_q, chain_q, counters, spill, total;
+};
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// Queues the whole launch sequence of one batch on `s_` (no host synchronisation, no allocation): camera rays, then per
+// level hit set-up + secondary rays, then the two resolve passes into the strip.
+struct BatchGrids {
+    uint32_t raygen, secondary, aux_max;
+};
+extern "C++" {
+template <class EvBegin, class EvEnd>
+static void queue_batch(const FrameParams& fp, const BatchParams& bp, const WorkView& w, const BatchGrids& g, bool count,
+                        uint32_t max_depth, uint8_t* strip_dev, uint32_t* ids_obj_dev, uint32_t* ids_tri_dev, hipStream_t s_,
+                        EvBegin&& ev_begin, EvEnd&& ev_end) {
+    uint32_t* cw = (uint32_t*)w.counters;
+    unsigned long long* kc = (unsigned long long*)((char*)w.counters + CW_WORDS * 4);
+    const uint32_t aux_grid = std::min<uint32_t>(g.aux_max, (bp.n_samples + 255) / 256);
+    TraceIO tio{};
+    tio.hits = w.hits;
+    tio.occ = w.occ;
+    tio.counters = kc;
+    tio.spill = w.spill;
+    tio.work_counter = cw + CW_WORK + 0;
+    tio.term = w.term;
+    tio.nlev = w.nlev;
+    tio.first_obj = ids_obj_dev;
+    tio.first_tri = ids_tri_dev;
+    ev_begin(0, s_);
+    launch_trace(true, count, g.raygen, s_, fp, bp, tio);
+    ev_end(s_);
+    // max_depth == 0: one setup pass turns every sample into skybox(ray.direction) (mod.rs:125-127), no secondary rays
+    for (uint32_t lvl = 0; lvl < std::max(1u, max_depth); ++lvl) {
+        SetupIO sio{};
+        sio.chain_in = w.chain_q[lvl & 1];
+        sio.n_chain_in = cw + CW_NCHAIN + lvl;
+        sio.hits = w.hits;
+        sio.level = w.level;
+        sio.term = w.term;
+        sio.nlev = w.nlev;
+        sio.shadow_out = w.shadow_q;
+        sio.n_shadow_out = cw + CW_NSHADOW + lvl;
+        sio.chain_out = w.chain_q[(lvl + 1) & 1];
+        sio.n_chain_out = cw + CW_NCHAIN + lvl + 1;
+        ev_begin(1, s_);
+        launch_setup(lvl == 0, aux_grid, s_, fp, bp, sio, lvl);
+        ev_end(s_);
+        if (max_depth == 0) break;
+        TraceIO t2 = tio;
+        t2.shadow_q = w.shadow_q;
+        t2.n_shadow = cw + CW_NSHADOW + lvl;
+        t2.chain_q = w.chain_q[(lvl + 1) & 1];
+        t2.n_chain = cw + CW_NCHAIN + lvl + 1;
+        t2.work_counter = cw + CW_WORK + lvl + 1;
+        t2.first_obj = nullptr;
+        t2.first_tri = nullptr;
+        ev_begin(0, s_);
+        launch_trace(false, count, g.secondary, s_, fp, bp, t2);
+        ev_end(s_);
+    }
+    ResolveIO rio{};
+    rio.level = w.level; rio.term = w.term; rio.term_out = w.term;
+    rio.nlev = w.nlev; rio.occ = w.occ; rio.strip = strip_dev;
+    ev_begin(1, s_);
+    launch_resolve(std::min<uint32_t>(g.aux_max * 4, (bp.n_samples + 255) / 256),
+                   std::min<uint32_t>(g.aux_max, (bp.n_pixels + 255) / 256), s_, fp, bp, rio);
+    ev_end(s_);
+}
+}   // extern "C++"
 
 // trr_render_blocks: batches of at most blocks_per_batch blocks, rendered in block order; after_batch runs on the host
 // once a batch's blocks are final in the strip (its stream has been waited for) and may end the render with an error.
@@ -937,9 +1077,6 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     const uint32_t D = std::max(1u, max_depth);
     // persistent trace grid: every CU gets as many 256-thread blocks as its registers / LDS admit
     // (each template instantiation has its own register count, hence its own number of resident blocks)
-    if (ctx->bpc[0][0] == 0)
-        for (int rg = 0; rg < 2; ++rg)
-            for (int cn = 0; cn < 2; ++cn) ctx->bpc[rg][cn] = std::max(1, std::min(trace_blocks_per_cu(rg != 0, cn != 0), 8));
     // Secondary-ray launches: the smaller of the two resident-block counts per CU (their fifth block was measured neutral
     // to slightly slower).  Camera-ray launches: two blocks per CU -- most camera rays are short and coherent, and the
     // slots they leave free let the other lanes' secondary launches in (grid sweep on MI355X: 4 -> 2 blocks per CU is
@@ -958,7 +1095,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     if (std::getenv("TRR_DEBUG"))
         std::fprintf(stderr, "trr: resident blocks per CU raygen %d secondary %d (count build: %d %d), lanes %u batches %llu\n",
                      ctx->bpc[1][0], ctx->bpc[0][0], ctx->bpc[1][1], ctx->bpc[0][1], lanes, (unsigned long long)want_batches);
-    const uint32_t aux_grid_max = (uint32_t)ctx->n_cu * 8;
+    const BatchGrids grids{grid_raygen, grid_secondary, (uint32_t)ctx->n_cu * 8};
     int rc;
     // `pool` work sets may be used by this call: its `lanes` consecutive ones starting at lane_base.  A single-batch frame
     // of a pipelined caller (TRR_FLAG_PIPELINED) takes the two sets in turn, so that consecutive frames, queued on
@@ -981,31 +1118,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
             return rc;
     }
 
-    FrameParams fp{};
-    fp.nodes = (const Node4*)sc->nodes.p; fp.tris = (const TriRec*)sc->tris.p; fp.interp = (const InterpRec*)sc->interp.p;
-    fp.objs = (const ObjRec*)sc->objs.p; fp.mats = (const MatRec*)sc->mats.p; fp.texs = (const TexRec*)sc->texs.p;
-    fp.texels = (const uint8_t*)sc->texels.p; fp.lights = (const LightRec*)sc->lights.p;
-    fp.n_objs = sc->n_objs; fp.n_lights = L;
-    for (int k = 0; k < 3; ++k) {
-        fp.ambient[k] = sc->settings.ambient_color[k];
-        fp.sky_color[k] = sc->settings.skybox_color[k];
-        fp.cam_pos[k] = sc->camera.position[k];
-        fp.cam_x[k] = sc->cam_x[k]; fp.cam_y[k] = sc->cam_y[k]; fp.cam_z[k] = sc->cam_z[k];
-    }
-    fp.ambient_intensity = sc->settings.ambient_intensity;
-    fp.sky = sc->settings.skybox_is_image ? (const uint8_t*)sc->sky.p : nullptr;
-    fp.sky_w = sc->sky_w; fp.sky_h = sc->sky_h;
-    fp.aa = aa ? 1u : 0u;
-    fp.spp = spp;
-    {
-        float sq = std::sqrt((float)sc->settings.samples);   // mod.rs:226
-        fp.sqrt_spp = sq >= 4294967296.0f ? 0xFFFFFFFFu : (sq > 0.0f ? (uint32_t)sq : 0u);
-    }
-    fp.seed = sc->settings.seed;
-    fp.cam_focal = sc->cam_focal;
-    fp.width = tl.w; fp.height = tl.h; fp.bw = tl.bw; fp.bh = tl.bh; fp.nbx = tl.nbx; fp.nby = tl.nby;
-    fp.shard = shard; fp.n_shards = n_shards;
-    fp.delta = delta; fp.max_depth = max_depth;
+    const FrameParams fp = frame_params_of(sc, tl, shard, n_shards, delta, max_depth);
 
     const uint32_t n_batches = (n_owned + blocks_per_batch - 1) / blocks_per_batch;
     // statistics: per-launch events on the launch streams + one read-back of the queue / kernel counters per batch.
@@ -1065,8 +1178,6 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         if (cancel_flag && *cancel_flag) { result = TRR_ERR_CANCELLED; break; }   // render.rs:113
         trr_ctx::WorkSet& w = ctx->ws[(lane_base + bi % lanes) % pool];
         hipStream_t s_ = forked ? w.stream : st;
-        uint32_t* cw = (uint32_t*)w.counters.p;
-        unsigned long long* kc = (unsigned long long*)((char*)w.counters.p + CW_WORDS * 4);
         BatchParams bp{};
         bp.first_owned = bi * blocks_per_batch;
         bp.n_blocks = std::min(blocks_per_batch, n_owned - bp.first_owned);
@@ -1074,57 +1185,11 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         bp.n_samples = bp.n_pixels * spp;
         bp.cap = cap;
         HIPCHK(ctx, hipMemsetAsync(w.counters.p, 0, RB_STRIDE, s_));
-        const uint32_t aux_grid = std::min<uint32_t>(aux_grid_max, (bp.n_samples + 255) / 256);
-
-        TraceIO tio{};
-        tio.hits = (HitRec*)w.hits.p;
-        tio.occ = (int32_t*)w.occ.p;
-        tio.counters = kc;
-        tio.spill = (uint2*)w.spill.p;
-        tio.work_counter = cw + CW_WORK + 0;
-        tio.term = (float*)w.term.p;
-        tio.nlev = (uint8_t*)w.nlev.p;
-        tio.first_obj = ids_obj_dev;
-        tio.first_tri = ids_tri_dev;
-        ev_begin(0, s_);
-        launch_trace(true, count, grid_raygen, s_, fp, bp, tio);
-        ev_end(s_);
-        // max_depth == 0: one setup pass turns every sample into skybox(ray.direction) (mod.rs:125-127), no secondary rays
-        for (uint32_t lvl = 0; lvl < std::max(1u, max_depth); ++lvl) {
-            SetupIO sio{};
-            sio.chain_in = (const RayRec*)w.chain_q[lvl & 1].p;
-            sio.n_chain_in = cw + CW_NCHAIN + lvl;
-            sio.hits = (const HitRec*)w.hits.p;
-            sio.level = (float*)w.level.p;
-            sio.term = (float*)w.term.p;
-            sio.nlev = (uint8_t*)w.nlev.p;
-            sio.shadow_out = (RayRec*)w.shadow_q.p;
-            sio.n_shadow_out = cw + CW_NSHADOW + lvl;
-            sio.chain_out = (RayRec*)w.chain_q[(lvl + 1) & 1].p;
-            sio.n_chain_out = cw + CW_NCHAIN + lvl + 1;
-            ev_begin(1, s_);
-            launch_setup(lvl == 0, aux_grid, s_, fp, bp, sio, lvl);
-            ev_end(s_);
-            if (max_depth == 0) break;
-            TraceIO t2 = tio;
-            t2.shadow_q = (const RayRec*)w.shadow_q.p;
-            t2.n_shadow = cw + CW_NSHADOW + lvl;
-            t2.chain_q = (const RayRec*)w.chain_q[(lvl + 1) & 1].p;
-            t2.n_chain = cw + CW_NCHAIN + lvl + 1;
-            t2.work_counter = cw + CW_WORK + lvl + 1;
-            t2.first_obj = nullptr;
-            t2.first_tri = nullptr;
-            ev_begin(0, s_);
-            launch_trace(false, count, grid_secondary, s_, fp, bp, t2);
-            ev_end(s_);
-        }
-        ResolveIO rio{};
-        rio.level = (const float*)w.level.p; rio.term = (const float*)w.term.p; rio.term_out = (float*)w.term.p;
-        rio.nlev = (const uint8_t*)w.nlev.p; rio.occ = (const int32_t*)w.occ.p; rio.strip = strip_dev;
-        ev_begin(1, s_);
-        launch_resolve(std::min<uint32_t>(aux_grid_max * 4, (bp.n_samples + 255) / 256),
-                       std::min<uint32_t>(aux_grid_max, (bp.n_pixels + 255) / 256), s_, fp, bp, rio);
-        ev_end(s_);
+        WorkView wv;
+        wv.hits = (HitRec*)w.hits.p; wv.level = (float*)w.level.p; wv.term = (float*)w.term.p; wv.nlev = (uint8_t*)w.nlev.p;
+        wv.occ = (int32_t*)w.occ.p; wv.shadow_q = (RayRec*)w.shadow_q.p; wv.chain_q[0] = (RayRec*)w.chain_q[0].p;
+        wv.chain_q[1] = (RayRec*)w.chain_q[1].p; wv.counters = w.counters.p; wv.spill = (uint2*)w.spill.p;
+        queue_batch(fp, bp, wv, grids, count, max_depth, strip_dev, ids_obj_dev, ids_tri_dev, s_, ev_begin, ev_end);
         HIPCHK(ctx, hipGetLastError());
         if (stats) HIPCHK(ctx, hipMemcpyAsync(pinned_base + rb_stride * bi, w.counters.p, rb_stride, hipMemcpyDeviceToHost, s_));
         ++batches_run;
@@ -1198,6 +1263,103 @@ int trr_render_shard_device(trr_ctx* ctx, trr_scene* scene, float delta, uint32_
     if (!ctx) return fail(nullptr, TRR_ERR_INVALID, "trr_render_shard_device: ctx is NULL");
     return render_shard_impl(ctx, scene, delta, max_depth, flags, shard, n_shards, (uint8_t*)strip_dev, strip_bytes,
                              stream ? (hipStream_t)stream : ctx->stream, nullptr, nullptr, cancel_flag, progress, user, stats_out);
+}
+
+// ---- the entry point that allocates nothing ------------------------------------------------------------------------------
+// Work set of `cap` samples carved out of a flat byte range: returns the bytes needed; fills *w when base != nullptr.
+static size_t carve_work_set(unsigned char* base, uint32_t cap, uint32_t D, uint32_t L, uint32_t spill_grid, WorkView* w) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char* p = base ? base + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    const uint32_t Lq = std::max(1u, L);
+    unsigned char* counters = take(RB_STRIDE);
+    unsigned char* spill = take(trace_spill_bytes(spill_grid));
+    unsigned char* hits = take((size_t)cap * sizeof(HitRec));
+    unsigned char* level = take((size_t)cap * 4 * LEVEL_PLANES * D);
+    unsigned char* term = take((size_t)cap * 12);
+    unsigned char* nlev = take((size_t)cap);
+    unsigned char* occ = take((size_t)cap * 4 * Lq * D);
+    unsigned char* shadow_q = take((size_t)cap * sizeof(RayRec) * Lq);
+    unsigned char* chain0 = take((size_t)cap * sizeof(RayRec));
+    unsigned char* chain1 = take((size_t)cap * sizeof(RayRec));
+    if (w) {
+        w->counters = counters; w->spill = (uint2*)spill; w->hits = (HitRec*)hits; w->level = (float*)level;
+        w->term = (float*)term; w->nlev = (uint8_t*)nlev; w->occ = (int32_t*)occ; w->shadow_q = (RayRec*)shadow_q;
+        w->chain_q[0] = (RayRec*)chain0; w->chain_q[1] = (RayRec*)chain1;
+    }
+    return off;
+}
+
+size_t trr_noalloc_scratch_bytes(void) { return SCRATCH_BYTES; }
+
+int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t max_depth, uint32_t shard, uint32_t n_shards,
+                                    void* strip_dev, size_t strip_bytes, void* stream) {
+    if (!ctx || !sc) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: NULL context or scene");
+    if (sc->ctx != ctx) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: scene belongs to another context");
+    if (!sc->have_camera || !sc->have_settings) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: camera/settings not set");
+    if (!(delta >= 0.0f)) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: delta must be >= 0");
+    if (max_depth > 254) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: max_depth above 254");
+    if (n_shards == 0 || shard >= n_shards) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: bad shard / n_shards");
+    if (!ctx->scratch) return fail(ctx, TRR_ERR_DEVICE, "trr_render_shard_device_noalloc: the scratch array has no device address");
+    Tiling tl;
+    if (!tiling_of(sc->camera.width, sc->camera.height, &tl))
+        return fail(ctx, TRR_ERR_RESOLUTION, "trr_render_shard_device_noalloc: width and height must be >= 20 (render.rs:109)");
+    const size_t need_strip = (size_t)max_owned_blocks(tl, n_shards) * tl.bw * tl.bh * 3;
+    if (!strip_dev || strip_bytes < need_strip) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: strip buffer too small");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+
+    const bool aa = sc->settings.anti_aliasing != 0;
+    const uint32_t spp = aa ? sc->settings.samples : 1u;
+    const uint32_t L = sc->n_lights, D = std::max(1u, max_depth);
+    const uint32_t n_owned = owned_blocks(tl, shard, n_shards);
+    const uint64_t spb = (uint64_t)tl.bw * tl.bh * spp;   // samples per block
+    HIPCHK(ctx, hipMemsetAsync(strip_dev, 0, need_strip, st));
+    if (spp == 0 || n_owned == 0) return TRR_OK;   // mod.rs:228-249 with samples == 0: NaN mean -> 0 (render.rs:136)
+
+    // two resident blocks per CU for both kinds of launch: the spill area of the whole grid must fit the scratch array too
+    BatchGrids grids;
+    grids.raygen = grids.secondary = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::min(2, std::min(ctx->bpc[0][0], ctx->bpc[1][0]));
+    grids.aux_max = (uint32_t)ctx->n_cu * 8;
+    const uint32_t spill_grid = grids.raygen;
+    // the largest whole number of blocks per batch whose work set fits the scratch array
+    const size_t fixed = carve_work_set(nullptr, 0, D, L, spill_grid, nullptr);
+    const size_t per_64 = carve_work_set(nullptr, 64, D, L, spill_grid, nullptr) - fixed;   // an upper bound per 64 samples (alignment included)
+    if (fixed >= SCRATCH_BYTES || spb > (1ull << 25))
+        return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: one block of this frame exceeds the static scratch array");
+    const uint64_t max_samples = (uint64_t)((SCRATCH_BYTES - fixed) / per_64) * 64;
+    uint32_t blocks_per_batch = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(max_samples, 1ull << 25) / spb, n_owned);
+    if (blocks_per_batch == 0)
+        return fail(ctx, TRR_ERR_INVALID,
+                    "trr_render_shard_device_noalloc: one block (" + std::to_string(spb) + " samples at " + std::to_string(L) + " lights, max_depth " +
+                        std::to_string(max_depth) + ") needs more than the " + std::to_string(SCRATCH_BYTES >> 20) +
+                        " MiB static scratch array holds (" + std::to_string(max_samples) + " samples); use trr_render_shard_device");
+    const uint32_t cap = (uint32_t)(((uint64_t)blocks_per_batch * spb + 63) & ~63ull);
+    WorkView wv;
+    if (carve_work_set(ctx->scratch, cap, D, L, spill_grid, &wv) > SCRATCH_BYTES)
+        return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: work set does not fit the scratch array");
+
+    const FrameParams fp = frame_params_of(sc, tl, shard, n_shards, delta, max_depth);
+    const uint32_t bpix = tl.bw * tl.bh;
+    auto no_ev_begin = [](uint8_t, hipStream_t) {};
+    auto no_ev_end = [](hipStream_t) {};
+    // batches run one after the other on the caller's stream and share the one work set; the array keeps the last call's
+    // contents, so what must start at zero (queue sizes, work counters) is cleared before every batch
+    for (uint32_t first = 0; first < n_owned; first += blocks_per_batch) {
+        BatchParams bp{};
+        bp.first_owned = first;
+        bp.n_blocks = std::min(blocks_per_batch, n_owned - first);
+        bp.n_pixels = bp.n_blocks * bpix;
+        bp.n_samples = bp.n_pixels * spp;
+        bp.cap = cap;
+        HIPCHK(ctx, hipMemsetAsync(wv.counters, 0, RB_STRIDE, st));
+        queue_batch(fp, bp, wv, grids, false, max_depth, (uint8_t*)strip_dev, nullptr, nullptr, st, no_ev_begin, no_ev_end);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return TRR_OK;
 }
 
 int trr_assemble_device(trr_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_shards, const void* strips_dev, void* frame_dev,

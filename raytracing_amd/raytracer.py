@@ -276,6 +276,15 @@ class Raytracer:
             raise ZeroDivisionError("resolution below 20 pixels: the reference divides by zero (render.rs:109)")
         N.check(rc, self.ctx.handle)
 
+    def render_shard_device_noalloc(self, shard: int, n_shards: int, strip_ptr: int, strip_bytes: int, stream: Optional[int] = None):
+        """``render_shard_device`` for callers that cannot allocate (trr_render_shard_device_noalloc): all work buffers come
+        from the library's static 256 MiB device array; raises NativeError(TRR_ERR_INVALID) when one block does not fit."""
+        rc = N.lib().trr_render_shard_device_noalloc(self.ctx.handle, self._scene, self.delta, self.max_depth, int(shard),
+                                                     int(n_shards), strip_ptr, int(strip_bytes), stream)
+        if rc == N.TRR_ERR_RESOLUTION:
+            raise ZeroDivisionError("resolution below 20 pixels: the reference divides by zero (render.rs:109)")
+        N.check(rc, self.ctx.handle)
+
     def assemble_device(self, n_shards: int, strips_ptr: int, frame_ptr: int, stream: Optional[int] = None):
         N.check(N.lib().trr_assemble_device(self.ctx.handle, self.width, self.height, int(n_shards), strips_ptr, frame_ptr,
                                             stream), self.ctx.handle)
