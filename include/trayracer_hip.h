@@ -125,6 +125,7 @@ typedef struct trr_stats {
     uint64_t wave_trans_steps;     /* executions of the transition block (ray start / object change / ray end) per wavefront */
     uint64_t trans_lanes;          /* lanes that took part in them */
     uint64_t wave_uniform_node_steps; /* inner-node iterations in which every participating lane stood on the same node */
+    uint64_t queue_overflows;      /* pushes beyond a wavefront's ray-queue capacity: always 0 (the capacity is a proven bound) */
 } trr_stats;
 
 typedef void (*trr_progress_cb)(void* user, uint32_t blocks_done, uint32_t blocks_total);

@@ -61,7 +61,7 @@ class Stats(C.Structure):
                 ("trace_launches", C.c_uint32), ("blocks_rendered", C.c_uint32),
                 ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64), ("wave_outer_steps", C.c_uint64),
                 ("wave_lane_steps", C.c_uint64), ("wave_trans_steps", C.c_uint64), ("trans_lanes", C.c_uint64),
-                ("wave_uniform_node_steps", C.c_uint64)]
+                ("wave_uniform_node_steps", C.c_uint64), ("queue_overflows", C.c_uint64)]
 
     def rays(self) -> int:
         return self.rays_primary + self.rays_shadow + self.rays_reflection + self.rays_march
@@ -153,10 +153,11 @@ def lib() -> C.CDLL:
     L.trr_render_blocks.argtypes = [vp, vp, f32, u32, u32, u32, vp, vp, vp, vp, vp]
     L.trr_render_shard_device.restype = i32
     L.trr_render_shard_device.argtypes = [vp, vp, f32, u32, u32, u32, u32, vp, C.c_size_t, vp, vp, vp, vp, vp]
-    L.trr_render_shard_device_noalloc.restype = i32
-    L.trr_render_shard_device_noalloc.argtypes = [vp, vp, f32, u32, u32, u32, vp, C.c_size_t, vp]
-    L.trr_noalloc_scratch_bytes.restype = C.c_size_t
-    L.trr_noalloc_scratch_bytes.argtypes = []
+    if hasattr(L, "trr_render_shard_device_noalloc"):   # (absent only from older builds loaded by the A/B experiment scripts)
+        L.trr_render_shard_device_noalloc.restype = i32
+        L.trr_render_shard_device_noalloc.argtypes = [vp, vp, f32, u32, u32, u32, vp, C.c_size_t, vp]
+        L.trr_noalloc_scratch_bytes.restype = C.c_size_t
+        L.trr_noalloc_scratch_bytes.argtypes = []
     L.trr_strip_bytes.restype = C.c_size_t
     L.trr_strip_bytes.argtypes = [u32, u32, u32]
     L.trr_assemble_device.restype = i32

@@ -66,7 +66,7 @@ struct trr_ctx {
     // Batches of blocks are pipelined over MAX_LANES work sets, each with its own stream: the persistent trace kernels
     // of one batch drain (few long rays left) while the next batch's kernels fill the freed CUs.
     struct WorkSet {
-        DevBuf hits, level, term, nlev, occ, shadow_q, chain_q[2], counters, spill;
+        DevBuf hits, level, term, nlev, color, occ, wqueue, gqueue, shadow_q, chain_q[2], counters, spill;
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
     };
@@ -75,7 +75,8 @@ struct trr_ctx {
     hipEvent_t fork = nullptr;
     DevBuf strip, frame, ids_obj, ids_tri;
     std::vector<hipEvent_t> events;
-    int bpc[2][2] = {{0, 0}, {0, 0}};    // resident 256-thread blocks per CU of k_trace<RAYGEN, COUNT> (occupancy query, once)
+    int bpc[2] = {0, 0};                 // resident 256-thread blocks per CU of k_trace<COUNT> (occupancy query, once)
+    int bpc_level[2][2] = {{0, 0}, {0, 0}};   // ... of k_trace_level<RAYGEN, COUNT>
     unsigned char* scratch = nullptr;    // this device's copy of the static `scratch` array (hipGetSymbolAddress in trr_create)
     uint32_t rotate = 0;                 // round-robin start lane of single-batch frames
     uint64_t budget_total = 0;           // bytes the work sets of all lanes may take together (set at the first render)
@@ -213,9 +214,10 @@ int trr_create(int device_id, trr_ctx** out) {
         trr_destroy(ctx);
         return fail(nullptr, TRR_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
     }
-    // resident 256-thread blocks per CU of the four k_trace instantiations (each has its own register count)
+    // resident 256-thread blocks per CU of the two k_trace instantiations (each has its own register count)
+    for (int cn = 0; cn < 2; ++cn) ctx->bpc[cn] = std::max(1, std::min(trace_blocks_per_cu(cn != 0), 8));
     for (int rg = 0; rg < 2; ++rg)
-        for (int cn = 0; cn < 2; ++cn) ctx->bpc[rg][cn] = std::max(1, std::min(trace_blocks_per_cu(rg != 0, cn != 0), 8));
+        for (int cn = 0; cn < 2; ++cn) ctx->bpc_level[rg][cn] = std::max(1, std::min(level_blocks_per_cu(rg != 0, cn != 0), 8));
     *out = ctx;
     return TRR_OK;
 }
@@ -225,7 +227,7 @@ void trr_destroy(trr_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto& w : ctx->ws) {
-        for (DevBuf* b : {&w.hits, &w.level, &w.term, &w.nlev, &w.occ, &w.shadow_q, &w.chain_q[0], &w.chain_q[1], &w.counters, &w.spill})
+        for (DevBuf* b : {&w.hits, &w.level, &w.term, &w.nlev, &w.color, &w.occ, &w.wqueue, &w.gqueue, &w.shadow_q, &w.chain_q[0], &w.chain_q[1], &w.counters, &w.spill})
             release(*b);
         if (w.done) (void)hipEventDestroy(w.done);
         if (w.stream) (void)hipStreamDestroy(w.stream);
@@ -390,7 +392,7 @@ static int build_scene_device(trr_ctx* ctx, trr_scene* sc, const trr_object_desc
         }
         std::string msg;
         hipError_t e = build_object_device(d.triangles, d.material_index, d.n_triangles, static_cast<const MatRec*>(sc->mats.p),
-                                           mat_bases[oi], d.n_materials, (uint32_t)node_base, (uint32_t)slot_base,
+                                           mat_bases[oi], d.n_materials, (uint32_t)node_base, (uint32_t)slot_base, (uint32_t)interp_base,
                                            static_cast<InterpRec*>(sc->interp.p) + interp_base, ctx->stream, &parts[oi], &msg);
         if (e != hipSuccess) {
             free_parts();
@@ -501,7 +503,7 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
                 TriRec& r = recs[t];
                 r.ax = a.x; r.ay = a.y; r.az = a.z; r.bx = b.x; r.by = b.y; r.bz = b.z; r.cx = c.x; r.cy = c.y; r.cz = c.z;
                 r.nx = n.x; r.ny = n.y; r.nz = n.z;
-                r.tri_id = t;
+                r.tri_id = (uint32_t)interp_base + t;
                 int32_t mi = d.material_index ? d.material_index[t] : -1;
                 r.mat = (mi >= 0 && (uint32_t)mi < d.n_materials) ? (int32_t)(mat_base + (uint32_t)mi) : -1;
                 r.len = len;
@@ -509,6 +511,7 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
                 if (r.mat >= 0) {
                     int il = mats[r.mat].illum;
                     if (il == 6 || il == 7) r.flags |= 1u;   // material.rs:51-53
+                    if (il == 3 || il == 4) r.flags |= 2u;   // material.rs:47-49
                 }
                 // a triangle with |ab x ac| == 0 can never be hit for any delta >= 0 (triangle.rs:56): left out of the tree
                 live[t] = !(len <= 0.0f);
@@ -679,15 +682,16 @@ int trr_scene_validate(trr_scene* sc) {
                 for (uint32_t s = first; s < first + cnt; ++s) {
                     if (slot_seen[s]++) return bad(oi, "triangle slot " + std::to_string(s) + " is in two leaves");
                     const TriRec& r = tris[s];
-                    if (r.tri_id >= o.n_tris) return bad(oi, "triangle id out of range in slot " + std::to_string(s));
-                    if (tri_seen[r.tri_id]++) return bad(oi, "triangle " + std::to_string(r.tri_id) + " is in two slots");
+                    const uint32_t tid = r.tri_id - o.tri_base;   // the record holds tri_base + row
+                    if (r.tri_id < o.tri_base || tid >= o.n_tris) return bad(oi, "triangle id out of range in slot " + std::to_string(s));
+                    if (tri_seen[tid]++) return bad(oi, "triangle " + std::to_string(tid) + " is in two slots");
                     if (!it.has_box) continue;
                     const float a[3] = {r.ax, r.ay, r.az}, b[3] = {r.bx, r.by, r.bz}, c[3] = {r.cx, r.cy, r.cz};
                     for (int k = 0; k < 3; ++k) {   // triangle.rs:88-95
                         float c2 = c[k] + 0.0001f;
                         float lo = std::fmin(std::fmin(a[k], b[k]), c2), hi = std::fmax(std::fmax(a[k], b[k]), c2);
                         if (!ge(lo, it.box.lo[k]) || !ge(it.box.hi[k], hi))
-                            return bad(oi, "leaf box does not contain triangle " + std::to_string(r.tri_id));
+                            return bad(oi, "leaf box does not contain triangle " + std::to_string(tid));
                     }
                 }
                 continue;
@@ -844,11 +848,14 @@ static hipEvent_t get_event(trr_ctx* ctx, size_t i) {
     return ctx->events[i];
 }
 
-// counters block layout (uint32 words): [CW_WORK + i] work counter of the i-th trace launch (i <= max_depth),
-// [CW_NSHADOW + lvl] shadow rays emitted at level lvl, [CW_NCHAIN + lvl] chain rays entering level lvl;
-// the 64-bit kernel counters follow at byte offset CW_WORDS*4.
-enum { CW_WORK = 0, CW_NSHADOW = 288, CW_NCHAIN = 576, CW_WORDS = 1024 };
-static constexpr size_t RB_STRIDE = CW_WORDS * 4 + 96;   // per batch: queue counters + up to 12 kernel counters
+// counters block of one batch (uint32 words, cleared by ONE memset): [CW_WORK + i] work counter of the batch's i-th trace
+// launch (work items claimed), [CW_NSHADOW + lvl] / [CW_NCHAIN + lvl] shadow rays emitted at / chain rays entering level
+// lvl (level-synchronous schedule), [CW_SPILL + k] entries spilled by launch k (persistent schedule); the 64-bit kernel
+// counters (device_types.h KC_*) follow at byte offset CW_WORDS*4.
+enum { CW_WORK = 0, CW_NSHADOW = 288, CW_NCHAIN = 576, CW_SPILL = 864, CW_WORDS = 1024 };
+static constexpr uint32_t MAX_FOLLOWUPS = 7;
+static constexpr size_t RB_STRIDE = CW_WORDS * 4 + 8 * 16;   // per batch: launch / queue counters + up to 16 kernel counters
+static_assert(KC_COUNT <= 16, "kernel counters outgrew the read-back block");
 
 static int acquire_pinned(trr_ctx* ctx, size_t bytes, int* slot) {
     for (size_t i = 0; i < ctx->pinned.size(); ++i)
@@ -871,19 +878,17 @@ static void finish_stats(trr_ctx* ctx, const trr_ctx::PendingStats& f) {
     trr_stats* stats = f.out;
     const char* base = (const char*)ctx->pinned[f.pinned_slot].p;
     for (uint32_t bi = 0; bi < f.batches; ++bi) {
-        const uint32_t* w = (const uint32_t*)(base + RB_STRIDE * bi);
         const unsigned long long* k = (const unsigned long long*)(base + RB_STRIDE * bi + CW_WORDS * 4);
         uint32_t first = bi * f.blocks_per_batch;
         uint32_t nb = std::min(f.blocks_per_batch, f.n_owned - first);
         stats->rays_primary += (uint64_t)nb * f.bpix * f.spp;
-        for (uint32_t lvl = 0; lvl < f.max_depth; ++lvl) {
-            stats->rays_shadow += w[CW_NSHADOW + lvl];
-            stats->rays_reflection += w[CW_NCHAIN + lvl + 1];
-        }
-        stats->node_visits += k[0]; stats->box_tests += k[1]; stats->tri_tests += k[2]; stats->rays_march += k[3];
-        stats->wave_node_steps += k[4]; stats->wave_tri_steps += k[5]; stats->wave_outer_steps += k[6]; stats->wave_lane_steps += k[7];
-        stats->wave_trans_steps += k[8]; stats->trans_lanes += k[9];
-        stats->wave_uniform_node_steps += k[10];
+        stats->rays_shadow += k[KC_SHADOW_RAYS];
+        stats->rays_reflection += k[KC_CHAIN_RAYS];
+        stats->queue_overflows += k[KC_QUEUE_OVERFLOW];
+        stats->node_visits += k[KC_NODES]; stats->box_tests += k[KC_BOXES]; stats->tri_tests += k[KC_TRIS]; stats->rays_march += k[KC_MARCH];
+        stats->wave_node_steps += k[KC_WNODE]; stats->wave_tri_steps += k[KC_WTRI]; stats->wave_outer_steps += k[KC_WOUTER];
+        stats->wave_lane_steps += k[KC_WLANES]; stats->wave_trans_steps += k[KC_WTRANS]; stats->trans_lanes += k[KC_LTRANS];
+        stats->wave_uniform_node_steps += k[KC_WUNI];
     }
     float span = 0.0f;
     for (size_t i = 0; i + 1 < f.ev_count; i += 2) {
@@ -902,86 +907,158 @@ static void finish_stats(trr_ctx* ctx, const trr_ctx::PendingStats& f) {
 // points, carved out of the library's static scratch array by trr_render_shard_device_noalloc).
 struct WorkView {
     HitRec* hits = nullptr;
-    float* level = nullptr;
-    float* term = nullptr;
+    float4* level = nullptr;
+    float4* term = nullptr;
     uint8_t* nlev = nullptr;
+    float* color = nullptr;
     int32_t* occ = nullptr;
-    RayRec* shadow_q = nullptr;
-    RayRec* chain_q[2] = {nullptr, nullptr};
-    void* counters = nullptr;   // RB_STRIDE bytes: queue counters + kernel counters
+    // persistent schedule
+    float4* wqueue = nullptr;   // wave-local ray queues of the trace grid (32-B entries)
+    float4* gqueue = nullptr;   // two device-wide spill queues of spill_capacity() entries each (ping-pong between launches)
+    // level-synchronous schedule
+    float4* shadow_q = nullptr;     // [cap * L] 32-B ray records of one level's shadow rays
+    float4* chain_q[2] = {nullptr, nullptr};   // [cap] reflection rays entering the even / odd levels
+    void* counters = nullptr;   // RB_STRIDE bytes: work counter + kernel counters
     uint2* spill = nullptr;
 };
 
-// bytes of one work set for batches of `cap` samples (cap a multiple of 64), every buffer 256-B aligned
-struct WorkLayout {
-    size_t hits, level, term, nlev, occ, shadow_q, chain_q, counters, spill, total;
-};
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-// Queues the whole launch sequence of one batch on `s_` (no host synchronisation, no allocation): camera rays, then per
-// level hit set-up + secondary rays, then the two resolve passes into the strip.
+// Capacity of a wavefront's ray queue.  A wavefront takes camera rays only when its queue is empty, so at most 64 chains
+// are alive in it, and the queue is FIFO, so of each chain it holds at most the L shadow rays of its last hit plus its
+// next reflection ray: 64 * (L + 1) entries, rounded up to a power of two (the kernel masks indices).
+static uint32_t queue_capacity(uint32_t n_lights) {
+    uint32_t need = 64u * (n_lights + 1u), c = 128u;
+    while (c < need) c <<= 1;
+    return c;
+}
+
+// Capacity of one spill queue: from the moment a wavefront can claim no more work items, every ray it would queue is
+// spilled -- the children of its at most 64 rays in flight, L + 1 each (its own queue is empty at that moment, because
+// it claims only when the queue is drained).
+static uint32_t spill_capacity(uint32_t trace_grid, uint32_t n_lights) { return trace_grid * 4u * 64u * (n_lights + 1u); }
+
+// Two schedules of one batch, same results bit for bit (same arithmetic, same records):
+//  * SCHED_PERSISTENT: ONE trace launch; every wavefront shades the hits of its own rays and drains the shadow / reflection
+//    rays they spawn from a queue of its own before it claims more camera rays (k_trace).  No level barriers: best where
+//    the ramp-up and tail of a launch weigh more than the work in it (small frames, thin deep levels).
+//  * SCHED_LEVELS: one launch per ray population -- camera rays, then per level hit set-up + (shadow rays of the level and
+//    reflection rays of the next) -- with specialised kernels (k_trace_level, k_setup).  A ray costs less (thin ray start /
+//    end blocks, hit set-up with full wavefronts); 2 * max_depth + 1 dependent launches per batch.
+// choose_schedule() picks per call, from measurements.
+enum { SCHED_PERSISTENT = 0, SCHED_LEVELS = 1 };
 struct BatchGrids {
-    uint32_t raygen, secondary, aux_max;
+    uint32_t schedule;
+    uint32_t trace, aux_max;   // persistent trace grid; largest grid of the set-up / resolve kernels
+    uint32_t followups;        // persistent: launches after the first that drain what the launch before spilled (0 = none)
+    uint32_t chunk_min[2];     // persistent: smallest claim of work items per wavefront in the first / the follow-up launches
+    uint32_t raygen, secondary;   // levels: grids of the camera-ray and the secondary-ray launches
 };
+
+// Queues the launch sequence of one batch on `s_` (no host synchronisation, no allocation), then the two resolve passes
+// into the strip.
 extern "C++" {
 template <class EvBegin, class EvEnd>
 static void queue_batch(const FrameParams& fp, const BatchParams& bp, const WorkView& w, const BatchGrids& g, bool count,
-                        uint32_t max_depth, uint8_t* strip_dev, uint32_t* ids_obj_dev, uint32_t* ids_tri_dev, hipStream_t s_,
+                        uint8_t* strip_dev, uint32_t* ids_obj_dev, uint32_t* ids_tri_dev, hipStream_t s_,
                         EvBegin&& ev_begin, EvEnd&& ev_end) {
     uint32_t* cw = (uint32_t*)w.counters;
     unsigned long long* kc = (unsigned long long*)((char*)w.counters + CW_WORDS * 4);
-    const uint32_t aux_grid = std::min<uint32_t>(g.aux_max, (bp.n_samples + 255) / 256);
-    TraceIO tio{};
-    tio.hits = w.hits;
-    tio.occ = w.occ;
-    tio.counters = kc;
-    tio.spill = w.spill;
-    tio.work_counter = cw + CW_WORK + 0;
-    tio.term = w.term;
-    tio.nlev = w.nlev;
-    tio.first_obj = ids_obj_dev;
-    tio.first_tri = ids_tri_dev;
-    ev_begin(0, s_);
-    launch_trace(true, count, g.raygen, s_, fp, bp, tio);
-    ev_end(s_);
-    // max_depth == 0: one setup pass turns every sample into skybox(ray.direction) (mod.rs:125-127), no secondary rays
-    for (uint32_t lvl = 0; lvl < std::max(1u, max_depth); ++lvl) {
-        SetupIO sio{};
-        sio.chain_in = w.chain_q[lvl & 1];
-        sio.n_chain_in = cw + CW_NCHAIN + lvl;
-        sio.hits = w.hits;
-        sio.level = w.level;
-        sio.term = w.term;
-        sio.nlev = w.nlev;
-        sio.shadow_out = w.shadow_q;
-        sio.n_shadow_out = cw + CW_NSHADOW + lvl;
-        sio.chain_out = w.chain_q[(lvl + 1) & 1];
-        sio.n_chain_out = cw + CW_NCHAIN + lvl + 1;
-        ev_begin(1, s_);
-        launch_setup(lvl == 0, aux_grid, s_, fp, bp, sio, lvl);
-        ev_end(s_);
-        if (max_depth == 0) break;
-        TraceIO t2 = tio;
-        t2.shadow_q = w.shadow_q;
-        t2.n_shadow = cw + CW_NSHADOW + lvl;
-        t2.chain_q = w.chain_q[(lvl + 1) & 1];
-        t2.n_chain = cw + CW_NCHAIN + lvl + 1;
-        t2.work_counter = cw + CW_WORK + lvl + 1;
-        t2.first_obj = nullptr;
-        t2.first_tri = nullptr;
+    if (g.schedule == SCHED_PERSISTENT) {
+        TraceIO tio{};
+        tio.hits = w.hits;
+        tio.level = w.level;
+        tio.term = w.term;
+        tio.nlev = w.nlev;
+        tio.occ = w.occ;
+        tio.wqueue = w.wqueue;
+        tio.qcap = queue_capacity(fp.n_lights);
+        tio.first_obj = ids_obj_dev;
+        tio.first_tri = ids_tri_dev;
+        tio.counters = kc;
+        tio.spill = w.spill;
+        // Launch 0 takes the camera rays.  With follow-ups, a wavefront that can claim no more work items spills the rays
+        // it would queue, and launch k >= 1 deals what launch k - 1 spilled evenly over all wavefronts (the last one spills
+        // nothing; a chain is at most max_depth reflection rays long, so deeper follow-ups would find nothing).
+        const uint32_t scap = spill_capacity(g.trace, fp.n_lights);
+        const uint32_t n_follow = fp.max_depth == 0u ? 0u : std::min(std::min(g.followups, fp.max_depth), MAX_FOLLOWUPS);
+        for (uint32_t k = 0; k <= n_follow; ++k) {
+            tio.work_counter = cw + CW_WORK + k;
+            tio.src_q = k == 0 ? nullptr : w.gqueue + (size_t)((k - 1) & 1u) * scap * 2u;
+            tio.src_n = k == 0 ? nullptr : cw + CW_SPILL + (k - 1);
+            tio.src_cap = scap;
+            tio.spill_q = k == n_follow ? nullptr : w.gqueue + (size_t)(k & 1u) * scap * 2u;
+            tio.spill_n = k == n_follow ? nullptr : cw + CW_SPILL + k;
+            tio.spill_cap = scap;
+            tio.chunk_min = std::max(1u, g.chunk_min[k == 0 ? 0 : 1]);
+            ev_begin(0, s_);
+            launch_trace(count, g.trace, s_, fp, bp, tio);
+            ev_end(s_);
+        }
+    } else {
+        const uint32_t aux_grid = std::min<uint32_t>(g.aux_max, (bp.n_samples + 255) / 256);
+        LevelIO tio{};
+        tio.hits = w.hits;
+        tio.nlev = w.nlev;
+        tio.occ = w.occ;
+        tio.counters = kc;
+        tio.spill = w.spill;
+        tio.work_counter = cw + CW_WORK + 0;
+        tio.first_obj = ids_obj_dev;
+        tio.first_tri = ids_tri_dev;
         ev_begin(0, s_);
-        launch_trace(false, count, g.secondary, s_, fp, bp, t2);
+        launch_trace_level(true, count, g.raygen, s_, fp, bp, tio);
         ev_end(s_);
+        // max_depth == 0: one set-up pass turns every sample into skybox(ray.direction) (mod.rs:125-127), no secondary rays
+        for (uint32_t lvl = 0; lvl < std::max(1u, fp.max_depth); ++lvl) {
+            SetupIO sio{};
+            sio.chain_in = w.chain_q[lvl & 1];
+            sio.n_chain_in = cw + CW_NCHAIN + lvl;
+            sio.hits = w.hits;
+            sio.level = w.level;
+            sio.term = w.term;
+            sio.nlev = w.nlev;
+            sio.shadow_out = w.shadow_q;
+            sio.n_shadow_out = cw + CW_NSHADOW + lvl;
+            sio.chain_out = w.chain_q[(lvl + 1) & 1];
+            sio.n_chain_out = cw + CW_NCHAIN + lvl + 1;
+            sio.counters = kc;
+            ev_begin(1, s_);
+            launch_setup(lvl == 0, aux_grid, s_, fp, bp, sio, lvl);
+            ev_end(s_);
+            if (fp.max_depth == 0) break;
+            LevelIO t2 = tio;
+            t2.shadow_q = w.shadow_q;
+            t2.n_shadow = cw + CW_NSHADOW + lvl;
+            t2.chain_q = w.chain_q[(lvl + 1) & 1];
+            t2.n_chain = cw + CW_NCHAIN + lvl + 1;
+            t2.work_counter = cw + CW_WORK + lvl + 1;
+            t2.first_obj = nullptr;
+            t2.first_tri = nullptr;
+            ev_begin(0, s_);
+            launch_trace_level(false, count, g.secondary, s_, fp, bp, t2);
+            ev_end(s_);
+        }
     }
     ResolveIO rio{};
-    rio.level = w.level; rio.term = w.term; rio.term_out = w.term;
-    rio.nlev = w.nlev; rio.occ = w.occ; rio.strip = strip_dev;
+    rio.level = w.level; rio.term = w.term; rio.nlev = w.nlev; rio.color = w.color;
+    rio.occ = w.occ; rio.strip = strip_dev;
     ev_begin(1, s_);
     launch_resolve(std::min<uint32_t>(g.aux_max * 4, (bp.n_samples + 255) / 256),
                    std::min<uint32_t>(g.aux_max, (bp.n_pixels + 255) / 256), s_, fp, bp, rio);
     ev_end(s_);
 }
 }   // extern "C++"
+
+// Which schedule a call uses.  Measured on one MI355X (scripts/experiments/quick.py, two frames in flight, ms per frame,
+// levels / persistent): 800x600 2 objects max_depth 2: 1.42 / 1.64; 1080p max_depth 5: 1.64 / 1.33; 4K terrain 10 M
+// triangles: 2.23 / 2.32; 4K mirrors max_depth 9: 12.2 / 15.1; an eighth of the 4K x 16 spp frame: 4.9 / 6.1; that whole
+// frame: 30.8 / 39.  The persistent schedule wins only where many levels hold few rays each (deep max_depth, a frame of a
+// few million rays): the launches it saves then outweigh its dearer rays.  TRR_SCHEDULE=levels|persistent overrides.
+static uint32_t choose_schedule(uint64_t samples, uint32_t n_lights, uint32_t max_depth) {
+    if (const char* e = std::getenv("TRR_SCHEDULE")) return e[0] == 'l' ? SCHED_LEVELS : SCHED_PERSISTENT;
+    return (max_depth >= 4 && samples * (1ull + n_lights) <= (12ull << 20)) ? SCHED_PERSISTENT : SCHED_LEVELS;
+}
 
 // trr_render_blocks: batches of at most blocks_per_batch blocks, rendered in block order; after_batch runs on the host
 // once a batch's blocks are final in the strip (its stream has been waited for) and may end the render with an error.
@@ -1027,9 +1104,11 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
 
     // ---- batch sizing: batches are pipelined over `lanes` work sets (each its own stream + buffers) -------------
     const bool interactive = progress != nullptr || cancel_flag != nullptr || hook != nullptr;   // polled per batch: keep batches in order
-    const uint64_t per_sample = 32 /*hits*/ + 4ull * LEVEL_PLANES * std::max(1u, max_depth) + 12 + 1 +
-                                4ull * L * std::max(1u, max_depth) + 32ull * L + 64;
     const uint64_t spb = (uint64_t)bpix * spp;
+    const uint32_t schedule = choose_schedule((uint64_t)n_owned * spb, L, max_depth);
+    const uint64_t per_sample = sizeof(HitRec) + 16ull * LEVEL_F4 * std::max(1u, max_depth) + 16 + 1 + 12 +
+                                4ull * std::max(1u, L) * std::max(1u, max_depth) + 16 +
+                                (schedule == SCHED_LEVELS ? 32ull * std::max(1u, L) + 64 : 0);
     // Batch count (measured on MI355X, scripts/experiments/sweep_batches.py): few, large batches -- every persistent launch pays a
     // ramp-up and a tail of fixed length -- but at least two, on two lanes, so that one batch's tails and small deep-level
     // launches overlap the other's bulk; three lanes once there are four or more batches.  An odd batch per lane keeps
@@ -1075,27 +1154,36 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     if (hook && hook->blocks_per_batch) blocks_per_batch = std::min(blocks_per_batch, hook->blocks_per_batch);
     const uint32_t cap = (uint32_t)(((uint64_t)blocks_per_batch * spb + 63) & ~63ull);
     const uint32_t D = std::max(1u, max_depth);
-    // persistent trace grid: every CU gets as many 256-thread blocks as its registers / LDS admit
-    // (each template instantiation has its own register count, hence its own number of resident blocks)
-    // Secondary-ray launches: the smaller of the two resident-block counts per CU (their fifth block was measured neutral
-    // to slightly slower).  Camera-ray launches: two blocks per CU -- most camera rays are short and coherent, and the
-    // slots they leave free let the other lanes' secondary launches in (grid sweep on MI355X: 4 -> 2 blocks per CU is
-    // -4 % frame time for the whole 4K frame, -9 % for an eighth of it).  TRR_GRID_BPC="raygen,secondary" overrides.
-    const uint32_t trace_grid = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::min(ctx->bpc[1][count ? 1 : 0], ctx->bpc[0][count ? 1 : 0]);
-    uint32_t grid_raygen = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::min(2, ctx->bpc[1][count ? 1 : 0]);
-    uint32_t grid_secondary = trace_grid;
-    const uint32_t spill_grid = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::max(ctx->bpc[1][count ? 1 : 0], ctx->bpc[0][count ? 1 : 0]);
-    if (const char* e = std::getenv("TRR_GRID_BPC")) {   // experiments: blocks per CU of the raygen / secondary launches
-        int a = 0, b = 0;
-        if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) {
-            grid_raygen = (uint32_t)ctx->n_cu * (uint32_t)std::min(a, ctx->bpc[1][count ? 1 : 0]);
-            grid_secondary = (uint32_t)ctx->n_cu * (uint32_t)std::min(b, ctx->bpc[0][count ? 1 : 0]);
+    // Persistent trace grid: every CU gets as many 256-thread blocks as the kernel's registers / LDS admit, four at most (a
+    // fifth was measured neutral to slightly slower).  Level-synchronous schedule: secondary-ray launches the same,
+    // camera-ray launches two blocks per CU -- most camera rays are short and coherent, and the slots they leave free let
+    // the other lanes' secondary launches in (grid sweep on MI355X: 4 -> 2 blocks per CU is -4 % frame time for the whole
+    // 4K frame, -9 % for an eighth of it).  TRR_GRID_BPC="persistent,raygen,secondary" overrides (experiments).
+    const int cb = count ? 1 : 0;
+    int bpc_p = std::min(4, ctx->bpc[cb]), bpc_r = std::min(2, ctx->bpc_level[1][cb]);
+    int bpc_s = std::min(4, std::min(ctx->bpc_level[0][cb], ctx->bpc_level[1][cb]));
+    if (const char* e = std::getenv("TRR_GRID_BPC")) {
+        int a = 0, b = 0, c = 0;
+        if (std::sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) {
+            bpc_p = std::min(a, ctx->bpc[cb]); bpc_r = std::min(b, ctx->bpc_level[1][cb]); bpc_s = std::min(c, ctx->bpc_level[0][cb]);
         }
     }
+    const uint32_t n_cu = (uint32_t)std::max(1, ctx->n_cu);
+    BatchGrids grids{};
+    grids.schedule = schedule;
+    grids.trace = n_cu * (uint32_t)bpc_p;
+    grids.aux_max = n_cu * 8;
+    grids.followups = 0;
+    grids.chunk_min[0] = 64; grids.chunk_min[1] = 16;
+    grids.raygen = n_cu * (uint32_t)bpc_r;
+    grids.secondary = n_cu * (uint32_t)bpc_s;
+    if (const char* e = std::getenv("TRR_FOLLOWUPS")) grids.followups = (uint32_t)std::max(0, std::atoi(e));
+    const uint32_t trace_grid = schedule == SCHED_PERSISTENT ? grids.trace : std::max(grids.raygen, grids.secondary);   // sizes the stack-spill area
     if (std::getenv("TRR_DEBUG"))
-        std::fprintf(stderr, "trr: resident blocks per CU raygen %d secondary %d (count build: %d %d), lanes %u batches %llu\n",
-                     ctx->bpc[1][0], ctx->bpc[0][0], ctx->bpc[1][1], ctx->bpc[0][1], lanes, (unsigned long long)want_batches);
-    const BatchGrids grids{grid_raygen, grid_secondary, (uint32_t)ctx->n_cu * 8};
+        std::fprintf(stderr, "trr: schedule %s, resident blocks per CU persistent %d raygen %d secondary %d, lanes %u batches %llu\n",
+                     schedule == SCHED_LEVELS ? "levels" : "persistent", ctx->bpc[cb], ctx->bpc_level[1][cb], ctx->bpc_level[0][cb], lanes,
+                     (unsigned long long)want_batches);
+    const uint32_t qcap = queue_capacity(L);
     int rc;
     // `pool` work sets may be used by this call: its `lanes` consecutive ones starting at lane_base.  A single-batch frame
     // of a pipelined caller (TRR_FLAG_PIPELINED) takes the two sets in turn, so that consecutive frames, queued on
@@ -1108,14 +1196,20 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     }
     for (uint32_t k = 0; k < pool; ++k) {
         trr_ctx::WorkSet& w = ctx->ws[k];
-        if ((rc = ensure(ctx, w.hits, (size_t)cap * sizeof(HitRec))) || (rc = ensure(ctx, w.level, (size_t)cap * 4 * LEVEL_PLANES * D)) ||
-            (rc = ensure(ctx, w.term, (size_t)cap * 12)) || (rc = ensure(ctx, w.nlev, (size_t)cap)) ||
-            (rc = ensure(ctx, w.occ, (size_t)cap * 4 * std::max(1u, L) * D)) ||
-            (rc = ensure(ctx, w.shadow_q, (size_t)cap * sizeof(RayRec) * std::max(1u, L))) ||
-            (rc = ensure(ctx, w.chain_q[0], (size_t)cap * sizeof(RayRec))) ||
-            (rc = ensure(ctx, w.chain_q[1], (size_t)cap * sizeof(RayRec))) || (rc = ensure(ctx, w.counters, RB_STRIDE)) ||
-            (rc = ensure(ctx, w.spill, trace_spill_bytes(spill_grid))))
+        if ((rc = ensure(ctx, w.hits, (size_t)cap * sizeof(HitRec))) || (rc = ensure(ctx, w.level, (size_t)cap * 16 * LEVEL_F4 * D)) ||
+            (rc = ensure(ctx, w.term, (size_t)cap * 16)) || (rc = ensure(ctx, w.nlev, (size_t)cap)) || (rc = ensure(ctx, w.color, (size_t)cap * 12)) ||
+            (rc = ensure(ctx, w.occ, (size_t)cap * 4 * std::max(1u, L) * D)) || (rc = ensure(ctx, w.counters, RB_STRIDE)) ||
+            (rc = ensure(ctx, w.spill, trace_spill_bytes(trace_grid))))
             return rc;
+        if (schedule == SCHED_PERSISTENT) {
+            if ((rc = ensure(ctx, w.wqueue, trace_queue_bytes(trace_grid, qcap))) ||
+                (rc = ensure(ctx, w.gqueue, grids.followups ? 2 * (size_t)spill_capacity(trace_grid, L) * 32 : 256)))
+                return rc;
+        } else {
+            if ((rc = ensure(ctx, w.shadow_q, (size_t)cap * 32 * std::max(1u, L))) || (rc = ensure(ctx, w.chain_q[0], (size_t)cap * 32)) ||
+                (rc = ensure(ctx, w.chain_q[1], (size_t)cap * 32)))
+                return rc;
+        }
     }
 
     const FrameParams fp = frame_params_of(sc, tl, shard, n_shards, delta, max_depth);
@@ -1186,10 +1280,10 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         bp.cap = cap;
         HIPCHK(ctx, hipMemsetAsync(w.counters.p, 0, RB_STRIDE, s_));
         WorkView wv;
-        wv.hits = (HitRec*)w.hits.p; wv.level = (float*)w.level.p; wv.term = (float*)w.term.p; wv.nlev = (uint8_t*)w.nlev.p;
-        wv.occ = (int32_t*)w.occ.p; wv.shadow_q = (RayRec*)w.shadow_q.p; wv.chain_q[0] = (RayRec*)w.chain_q[0].p;
-        wv.chain_q[1] = (RayRec*)w.chain_q[1].p; wv.counters = w.counters.p; wv.spill = (uint2*)w.spill.p;
-        queue_batch(fp, bp, wv, grids, count, max_depth, strip_dev, ids_obj_dev, ids_tri_dev, s_, ev_begin, ev_end);
+        wv.hits = (HitRec*)w.hits.p; wv.level = (float4*)w.level.p; wv.term = (float4*)w.term.p; wv.nlev = (uint8_t*)w.nlev.p; wv.color = (float*)w.color.p;
+        wv.occ = (int32_t*)w.occ.p; wv.wqueue = (float4*)w.wqueue.p; wv.gqueue = (float4*)w.gqueue.p; wv.shadow_q = (float4*)w.shadow_q.p;
+        wv.chain_q[0] = (float4*)w.chain_q[0].p; wv.chain_q[1] = (float4*)w.chain_q[1].p; wv.counters = w.counters.p; wv.spill = (uint2*)w.spill.p;
+        queue_batch(fp, bp, wv, grids, count, strip_dev, ids_obj_dev, ids_tri_dev, s_, ev_begin, ev_end);
         HIPCHK(ctx, hipGetLastError());
         if (stats) HIPCHK(ctx, hipMemcpyAsync(pinned_base + rb_stride * bi, w.counters.p, rb_stride, hipMemcpyDeviceToHost, s_));
         ++batches_run;
@@ -1267,7 +1361,8 @@ int trr_render_shard_device(trr_ctx* ctx, trr_scene* scene, float delta, uint32_
 
 // ---- the entry point that allocates nothing ------------------------------------------------------------------------------
 // Work set of `cap` samples carved out of a flat byte range: returns the bytes needed; fills *w when base != nullptr.
-static size_t carve_work_set(unsigned char* base, uint32_t cap, uint32_t D, uint32_t L, uint32_t spill_grid, WorkView* w) {
+static size_t carve_work_set(unsigned char* base, uint32_t cap, uint32_t D, uint32_t L, uint32_t schedule, uint32_t trace_grid,
+                             WorkView* w) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         unsigned char* p = base ? base + off : nullptr;
@@ -1276,19 +1371,21 @@ static size_t carve_work_set(unsigned char* base, uint32_t cap, uint32_t D, uint
     };
     const uint32_t Lq = std::max(1u, L);
     unsigned char* counters = take(RB_STRIDE);
-    unsigned char* spill = take(trace_spill_bytes(spill_grid));
+    unsigned char* spill = take(trace_spill_bytes(trace_grid));
+    unsigned char* wqueue = schedule == SCHED_PERSISTENT ? take(trace_queue_bytes(trace_grid, queue_capacity(L))) : nullptr;
     unsigned char* hits = take((size_t)cap * sizeof(HitRec));
-    unsigned char* level = take((size_t)cap * 4 * LEVEL_PLANES * D);
-    unsigned char* term = take((size_t)cap * 12);
+    unsigned char* level = take((size_t)cap * 16 * LEVEL_F4 * D);
+    unsigned char* term = take((size_t)cap * 16);
     unsigned char* nlev = take((size_t)cap);
+    unsigned char* color = take((size_t)cap * 12);
     unsigned char* occ = take((size_t)cap * 4 * Lq * D);
-    unsigned char* shadow_q = take((size_t)cap * sizeof(RayRec) * Lq);
-    unsigned char* chain0 = take((size_t)cap * sizeof(RayRec));
-    unsigned char* chain1 = take((size_t)cap * sizeof(RayRec));
+    unsigned char* shadow_q = schedule == SCHED_LEVELS ? take((size_t)cap * 32 * Lq) : nullptr;
+    unsigned char* chain0 = schedule == SCHED_LEVELS ? take((size_t)cap * 32) : nullptr;
+    unsigned char* chain1 = schedule == SCHED_LEVELS ? take((size_t)cap * 32) : nullptr;
     if (w) {
-        w->counters = counters; w->spill = (uint2*)spill; w->hits = (HitRec*)hits; w->level = (float*)level;
-        w->term = (float*)term; w->nlev = (uint8_t*)nlev; w->occ = (int32_t*)occ; w->shadow_q = (RayRec*)shadow_q;
-        w->chain_q[0] = (RayRec*)chain0; w->chain_q[1] = (RayRec*)chain1;
+        w->counters = counters; w->spill = (uint2*)spill; w->wqueue = (float4*)wqueue; w->gqueue = nullptr; w->hits = (HitRec*)hits;
+        w->level = (float4*)level; w->term = (float4*)term; w->nlev = (uint8_t*)nlev; w->color = (float*)color; w->occ = (int32_t*)occ;
+        w->shadow_q = (float4*)shadow_q; w->chain_q[0] = (float4*)chain0; w->chain_q[1] = (float4*)chain1;
     }
     return off;
 }
@@ -1320,14 +1417,21 @@ int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, ui
     HIPCHK(ctx, hipMemsetAsync(strip_dev, 0, need_strip, st));
     if (spp == 0 || n_owned == 0) return TRR_OK;   // mod.rs:228-249 with samples == 0: NaN mean -> 0 (render.rs:136)
 
-    // two resident blocks per CU for both kinds of launch: the spill area of the whole grid must fit the scratch array too
-    BatchGrids grids;
-    grids.raygen = grids.secondary = (uint32_t)std::max(1, ctx->n_cu) * (uint32_t)std::min(2, std::min(ctx->bpc[0][0], ctx->bpc[1][0]));
-    grids.aux_max = (uint32_t)ctx->n_cu * 8;
-    const uint32_t spill_grid = grids.raygen;
+    // two resident blocks per CU for every trace launch: the stack-spill area (and, in the persistent schedule, the ray
+    // queues) of the whole grid must fit the scratch array too; no follow-up launches (no spill queues)
+    const uint32_t schedule = choose_schedule((uint64_t)n_owned * spb, L, max_depth);
+    const uint32_t n_cu = (uint32_t)std::max(1, ctx->n_cu);
+    BatchGrids grids{};
+    grids.schedule = schedule;
+    grids.trace = n_cu * (uint32_t)std::min(2, ctx->bpc[0]);
+    grids.raygen = grids.secondary = n_cu * (uint32_t)std::min(2, std::min(ctx->bpc_level[0][0], ctx->bpc_level[1][0]));
+    grids.aux_max = n_cu * 8;
+    grids.followups = 0;
+    grids.chunk_min[0] = 64; grids.chunk_min[1] = 16;
+    const uint32_t spill_grid = schedule == SCHED_PERSISTENT ? grids.trace : grids.raygen;
     // the largest whole number of blocks per batch whose work set fits the scratch array
-    const size_t fixed = carve_work_set(nullptr, 0, D, L, spill_grid, nullptr);
-    const size_t per_64 = carve_work_set(nullptr, 64, D, L, spill_grid, nullptr) - fixed;   // an upper bound per 64 samples (alignment included)
+    const size_t fixed = carve_work_set(nullptr, 0, D, L, schedule, spill_grid, nullptr);
+    const size_t per_64 = carve_work_set(nullptr, 64, D, L, schedule, spill_grid, nullptr) - fixed;   // an upper bound per 64 samples (alignment included)
     if (fixed >= SCRATCH_BYTES || spb > (1ull << 25))
         return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: one block of this frame exceeds the static scratch array");
     const uint64_t max_samples = (uint64_t)((SCRATCH_BYTES - fixed) / per_64) * 64;
@@ -1339,7 +1443,7 @@ int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, ui
                         " MiB static scratch array holds (" + std::to_string(max_samples) + " samples); use trr_render_shard_device");
     const uint32_t cap = (uint32_t)(((uint64_t)blocks_per_batch * spb + 63) & ~63ull);
     WorkView wv;
-    if (carve_work_set(ctx->scratch, cap, D, L, spill_grid, &wv) > SCRATCH_BYTES)
+    if (carve_work_set(ctx->scratch, cap, D, L, schedule, spill_grid, &wv) > SCRATCH_BYTES)
         return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: work set does not fit the scratch array");
 
     const FrameParams fp = frame_params_of(sc, tl, shard, n_shards, delta, max_depth);
@@ -1356,7 +1460,7 @@ int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, ui
         bp.n_samples = bp.n_pixels * spp;
         bp.cap = cap;
         HIPCHK(ctx, hipMemsetAsync(wv.counters, 0, RB_STRIDE, st));
-        queue_batch(fp, bp, wv, grids, false, max_depth, (uint8_t*)strip_dev, nullptr, nullptr, st, no_ev_begin, no_ev_end);
+        queue_batch(fp, bp, wv, grids, false, (uint8_t*)strip_dev, nullptr, nullptr, st, no_ev_begin, no_ev_end);
         HIPCHK(ctx, hipGetLastError());
     }
     return TRR_OK;

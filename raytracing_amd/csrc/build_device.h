@@ -27,7 +27,7 @@ struct DeviceBuildOut {
 // d_interp: where this object's nt InterpRecs go (final location).  Synchronous; returns hipSuccess or the first error
 // (err gets a description).
 hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uint32_t nt, const MatRec* d_mats, uint32_t mat_base,
-                               uint32_t n_mats_obj, uint32_t node_base, uint32_t slot_base, InterpRec* d_interp, hipStream_t stream,
+                               uint32_t n_mats_obj, uint32_t node_base, uint32_t slot_base, uint32_t tri_base, InterpRec* d_interp, hipStream_t stream,
                                DeviceBuildOut* out, std::string* err);
 
 }   // namespace trr

@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(BT) k_collapse(const uint2* __restrict__ q_in,
 
 __global__ void __launch_bounds__(BT) k_gather(const float* __restrict__ raw, const int32_t* __restrict__ matidx,
                                                const uint32_t* __restrict__ vals, uint32_t n_live, const MatRec* __restrict__ mats,
-                                               uint32_t mat_base, uint32_t n_mats_obj, const Box3* __restrict__ boxes,
+                                               uint32_t mat_base, uint32_t n_mats_obj, uint32_t tri_base, const Box3* __restrict__ boxes,
                                                TriRec* __restrict__ out, Box3* __restrict__ sorted_boxes) {
     const uint32_t s = blockIdx.x * BT + threadIdx.x;
     if (s >= n_live) return;
@@ -273,12 +273,13 @@ __global__ void __launch_bounds__(BT) k_gather(const float* __restrict__ raw, co
     if (mat >= 0) {
         int il = mats[mat].illum;
         if (il == 6 || il == 7) flags |= 1u;   // material.rs:51-53
+        if (il == 3 || il == 4) flags |= 2u;   // material.rs:47-49
     }
     float4* dst = reinterpret_cast<float4*>(out + s);
     dst[0] = make_float4(f[0], f[1], f[2], f[3]);
     dst[1] = make_float4(f[4], f[5], f[6], f[7]);
     dst[2] = make_float4(f[8], n[0], n[1], n[2]);
-    dst[3] = make_float4(__uint_as_float(t), __int_as_float(mat), len, __uint_as_float(flags));
+    dst[3] = make_float4(__uint_as_float(tri_base + t), __int_as_float(mat), len, __uint_as_float(flags));
 }
 
 struct Tmp {   // device allocations of one build, freed on every exit path
@@ -311,7 +312,7 @@ inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + BT - 1) / BT); }
     } while (0)
 
 hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uint32_t nt, const MatRec* d_mats, uint32_t mat_base,
-                               uint32_t n_mats_obj, uint32_t node_base, uint32_t slot_base, InterpRec* d_interp, hipStream_t stream,
+                               uint32_t n_mats_obj, uint32_t node_base, uint32_t slot_base, uint32_t tri_base, InterpRec* d_interp, hipStream_t stream,
                                DeviceBuildOut* out, std::string* err) {
     *out = DeviceBuildOut{};
     if (nt == 0) return hipSuccess;
@@ -388,7 +389,7 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
     BCK(tmp.get(&tris, n));
     BCK(tmp.get(&pyr_base, pyr_total));
     pyr.base = pyr_base;
-    hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(BT), 0, stream, raw, matidx, vals, n, d_mats, mat_base, n_mats_obj, boxes, tris,
+    hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(BT), 0, stream, raw, matidx, vals, n, d_mats, mat_base, n_mats_obj, tri_base, boxes, tris,
                        pyr_base);
     BCK(hipGetLastError());
 

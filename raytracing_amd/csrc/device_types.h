@@ -18,10 +18,10 @@ struct alignas(64) TriRec {
     float ax, ay, az, bx;
     float by, bz, cx, cy;
     float cz, nx, ny, nz;
-    uint32_t tri_id;    // row in the object's triangle array (the reference's Vec order)
+    uint32_t tri_id;    // obj.tri_base + row in the object's triangle array (the reference's Vec order) = index of the InterpRec
     int32_t mat;        // global material id, -1 = None
     float len;          // |ab x ac|; the kernel culls len <= delta (triangle.rs:56)
-    uint32_t flags;     // bit0: material is transparent (illum 6/7, material.rs:51-53)
+    uint32_t flags;     // bit0: material is transparent (illum 6/7, material.rs:51-53); bit1: reflective (illum 3/4, :47-49)
 };
 static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
 
@@ -69,30 +69,27 @@ struct LightRec {   // src/scene/light.rs:5-9
     float pad;
 };
 
-// Ray queue entry (32 B).  meta: bits 0..7 level, bit 8 shadow flag, bits 16..31 light index.
-struct alignas(16) RayRec {
-    float ox, oy, oz, dx;
-    float dy, dz;
-    uint32_t sample;
-    uint32_t meta;
-};
-static_assert(sizeof(RayRec) == 32, "RayRec must be 32 bytes");
-
-// Closest-hit result of a chain (camera / reflection) ray, indexed by queue position.
+// "Last hit so far" of a chain (camera / reflection) ray inside the transparency march (mod.rs:100-111), indexed by sample:
+// written only when a raycast ends on a transparent surface, read back only when the next raycast finds nothing.
 struct alignas(16) HitRec {
-    float ox, oy, oz;   // origin of the raycast that found the hit (advances during the transparency march, mod.rs:106);
-                        // k_setup re-evaluates the barycentric weights from it, the chain ray's direction and the slot
+    float ox, oy, oz;   // origin of the raycast that found the hit (advances during the march, mod.rs:106); the hit set-up
+                        // re-evaluates the barycentric weights from it, the chain ray's direction and the slot
     uint32_t slot;      // TriRec index, 0xFFFFFFFF = miss
     uint32_t obj;
-    uint32_t tri;       // triangle id (row in the object's triangle array) of the LAST hit of the march
-    uint32_t pad0;      // (the first-raycast ids go straight to the id buffers)
-    uint32_t pad1;
+    uint32_t tri;       // TriRec.tri_id (global) of the LAST hit of the march = index of its InterpRec
+    int32_t mat;        // TriRec.mat
+    uint32_t flags;     // TriRec.flags
 };
 static_assert(sizeof(HitRec) == 32, "HitRec must be 32 bytes");
 
-// Shaded-hit record of one chain level (src/raytracer/mod.rs:124-146 inputs), SoA planes of `cap` samples.
-// plane order: Px Py Pz Nx Ny Nz Dx Dy Dz diffR diffG diffB mat
-constexpr int LEVEL_PLANES = 13;
+// Shaded-hit record of one chain level (src/raytracer/mod.rs:124-146 inputs): 48 bytes per (level, sample), written by the
+// lane that shaded the hit as three 16-byte stores and read back as 16-byte loads (one for a shadow ray's origin):
+// (Px Py Pz Nx) (Ny Nz Dx Dy) (Dz tex_u tex_v mat); the diffuse colour is looked up by the resolve pass.
+constexpr int LEVEL_F4 = 3;
+
+// 64-bit kernel counters of one batch (behind the work counter in the batch's counter block)
+enum { KC_NODES = 0, KC_BOXES, KC_TRIS, KC_MARCH, KC_WNODE, KC_WTRI, KC_WOUTER, KC_WLANES, KC_WTRANS, KC_LTRANS, KC_WUNI,
+       KC_SHADOW_RAYS, KC_CHAIN_RAYS, KC_QUEUE_OVERFLOW, KC_COUNT };
 
 // Everything a kernel needs about the frame (passed by value).
 struct FrameParams {

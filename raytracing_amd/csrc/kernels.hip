@@ -1,13 +1,13 @@
 // kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the Trayracer hot path.
 //
-// Wavefront (queue-based) organisation, one HIP launch sequence per batch of image blocks, no host
-// round trip inside a batch (queue sizes stay in device memory):
+// Wavefront (queue-based) organisation, TWO kernels per batch of image blocks, no host round trip inside a batch:
 //
-//   k_trace<RAYGEN>      camera rays generated in-kernel  -> HitRec per sample        (mod.rs:250-255, camera.rs:30-42)
-//   for level = 0 .. max_depth-1:
-//     k_setup            HitRec -> shaded-hit record; emits L shadow rays + <=1 reflection ray   (mod.rs:124-153, 199-206)
-//     k_trace<QUEUE>     shadow rays + next level's reflection rays in ONE launch   (mod.rs:45-51, 96-114; object.rs:184-220)
-//   k_resolve_samples    deepest-first evaluation of shade_impl per sample that hit something   (mod.rs:141-211)
+//   k_trace              ONE persistent launch traces every ray of the batch: camera rays generated in-kernel
+//                        (mod.rs:250-255, camera.rs:30-42), closest hits with the transparency march (mod.rs:45-51, 96-114;
+//                        object.rs:184-220), and -- at the end of each chain ray -- the hit set-up (mod.rs:124-153, 199-206)
+//                        whose L shadow rays and <= 1 reflection ray go into the wavefront's OWN ray queue, which the same
+//                        wavefront drains before it claims more camera rays.  No level barriers, no ray records in HBM.
+//   k_resolve_samples    deepest-first evaluation of shade_impl per sample, incl. sky / texture look-ups  (mod.rs:57-93, 141-211)
 //   k_resolve_pixels     mean over a pixel's samples, RGB8                                     (mod.rs:248-249, render.rs:134-140)
 //
 // Arithmetic is IEEE fp32 with the reference's operation order; build with -ffp-contract=off (Rust never
@@ -163,7 +163,6 @@ DEV F3 primary_dir(const FrameParams& fp, uint32_t x, uint32_t y, uint32_t si) {
 // has finished are re-filled (ballot + one atomic per wavefront) once enough of them are idle.
 // ------------------------------------------------------------------------------------------------
 constexpr int TRACE_THREADS = 256;
-constexpr uint8_t NLEV_PENDING = 0xFF;   // nlev value of a camera sample whose hit waits for k_setup (max_depth <= 255 keeps it free)
 #ifdef TRR_WAVES_PER_EU
 #define TRR_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(TRR_WAVES_PER_EU, 8)))
 #else
@@ -238,39 +237,85 @@ DEV bool candidate_better(bool have, float key, uint32_t tri, float best_key, ui
     return key < best_key || (key == best_key && tri < best_tri);
 }
 
-template <bool RAYGEN, bool COUNT>
-__global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(FrameParams fp, BatchParams bp, TraceIO io) {
+// One entry of a ray queue (32 B = two 16-byte words): origin, direction, sample index inside the batch, meta (bits 0..7
+// level, bit 8 shadow flag, bits 16..31 light index).  A shadow entry of level k is the ray (P + L^*delta, L^) of
+// mod.rs:149-153 from the shaded hit of level k; a chain entry of level k >= 1 the reflection ray (P + N*delta,
+// reflect(D, N)) of mod.rs:203-206 from the hit of level k - 1.  The whole ray is in the entry so that a ray STARTS with one
+// memory round trip: the kernel is bound by the latency of dependent loads, not by bytes.
+constexpr uint32_t META_SHADOW = 0x100u;
+constexpr uint32_t TRI_FLAG_TRANSPARENT = 1u, TRI_FLAG_REFLECTIVE = 2u;   // TriRec.flags
+constexpr uint8_t NLEV_PENDING = 0xFF;   // nlev of a camera sample whose hit waits for k_setup (max_depth <= 254 keeps it free)
+constexpr uint32_t MARCH_CAP = 0xFFFFu;   // raycasts of one transparency march (mod.rs:100-111); the reference has no cap and
+                                          // would spin for ever on a ray that cannot advance (zero / NaN direction) -- the
+                                          // oracle shares this cap, which 3 276 scene units of glass would be needed to reach
+
+// The kernel's one argument.  The traversal steps of the loop need four of its scalars (nodes, tris, delta, n_objs); the
+// rest -- some 70 dwords -- is read only by the blocks that start and end rays.  Kept as ordinary kernel arguments they
+// all stay in scalar registers for the whole loop, which overflowed the 102 SGPRs (19 spilled into vector-register lanes,
+// 249 v_readlane / v_writelane in the loop, 134 VGPRs).  The ray start / end blocks therefore read their parameters from
+// the kernel-argument segment through a pointer that the optimiser cannot see through (cold_args), so those scalar loads
+// stay inside the blocks.
+struct TraceArgs {
+    FrameParams fp;
+    BatchParams bp;
+    TraceIO io;
+};
+DEV const TraceArgs* cold_args() {
+    auto p = (const TraceArgs __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const TraceArgs*)p;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(TraceArgs args) {
     __shared__ uint2 s_stack[STACK_LDS * TRACE_THREADS];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    uint2* my_spill = io.spill + ((size_t)blockIdx.x * TRACE_THREADS + tid) * STACK_SPILL;
-
-    uint32_t n_shadow = 0, total;
-    if (RAYGEN) total = bp.n_samples;
-    else {
-        n_shadow = *io.n_shadow;
-        total = n_shadow + *io.n_chain;
+    const uint32_t wave_global = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (TRACE_THREADS / 64) + tid / 64));
+    // the only parameters the traversal steps use
+    const Node4* const g_nodes = args.fp.nodes;
+    const TriRec* const g_tris = args.fp.tris;
+    const float delta = args.fp.delta;
+    const uint32_t n_objs = args.fp.n_objs;
+    uint2* my_spill;
+    uint32_t total, chunk_min, n_waves, chunk;
+    bool from_q;
+    {
+        const TraceArgs* ca = cold_args();
+        my_spill = ca->io.spill + ((size_t)blockIdx.x * TRACE_THREADS + tid) * STACK_SPILL;
+        // Work items of the launch: the batch's camera rays, or -- in a follow-up launch -- the queue entries that the
+        // launch before it spilled (io.src_q).  Once a wavefront can claim no more work items, everything it would push
+        // onto its own queue goes to the device-wide spill queue instead (io.spill_q, when present): the rays of the
+        // launch's tail are then dealt evenly over all wavefronts by the next launch (a kernel boundary makes them visible
+        // for free), instead of each wavefront finishing its own, very unequal, backlog.
+        from_q = ca->io.src_q != nullptr;
+        total = from_q ? min(*ca->io.src_n, ca->io.src_cap) : ca->bp.n_samples;
+        chunk_min = ca->io.chunk_min;
+        n_waves = gridDim.x * (TRACE_THREADS / 64);
+        // chunk (guided self-scheduling): a fraction of what is left per wavefront, between chunk_min and CHUNK_MAX items,
+        // so that claims are rare while there is plenty of work and fine-grained near the end of the launch
+        chunk = max(chunk_min, min(CHUNK_MAX, total / (n_waves * CHUNK_DIV)));
     }
+    // This wavefront's ray queue is a ring of io.qcap entries at io.wqueue + wave_global * io.qcap that only this wavefront
+    // reads and writes, so no store has to become visible to another CU inside the launch (per-XCD L2s are not coherent
+    // with each other).
+    uint32_t q_head = 0, q_tail = 0;   // wave-uniform, free-running
 
-    // a launch with little (or no) work: wavefronts beyond one per 64 items leave before touching the work counter
+    // a launch with little (or no) work: wavefronts beyond one per chunk_min items leave before touching the work counter
     // (5120 same-address atomics cost ~40 us, which is most of an empty launch)
-    if ((blockIdx.x * (TRACE_THREADS / 64) + tid / 64) * 64u >= total) return;
+    if (wave_global * chunk_min >= total) return;
 
     // ---- per-lane state (results go to memory as soon as a raycast ends; only the winner's slot/key stay live) ----
     // Per-lane booleans live in ONE register (bits of `fl`), and "this lane has no ray" is a value of `cur` (REF_IDLE):
     // as separate bools they become SGPR lane masks that hipcc re-merges at every join of the loop (3 scalar
-    // instructions per bool and join, ~100 per iteration).
+    // instructions per bool and join, ~100 per iteration).  Bits 16..31 of `fl` count the raycasts of the march.
     constexpr uint32_t F_FIRST = 1u, F_GHAVE = 2u, F_OHAVE = 4u, F_SKIPBOX = 8u;
     constexpr uint32_t REF_IDLE = 0xFFFFFFFEu;           // never a leaf reference: slots stay below 2^29 - 1 (api.hip)
     uint32_t fl = 0;
     bool exhausted = false, last_chunk = false;          // wave-uniform
-    uint32_t w_next = 0, w_end = 0;                      // wave-uniform: this wavefront's claimed range of work items
-    // chunk (guided self-scheduling): a fraction of what is left per wavefront, between one wavefront's worth and CHUNK_MAX
-    // items, so that claims are rare while there is plenty of work and fine-grained near the end of the launch
-    const uint32_t n_waves = gridDim.x * (TRACE_THREADS / 64);
-    uint32_t chunk = max(64u, min(CHUNK_MAX, total / (n_waves * CHUNK_DIV)));
+    uint32_t w_next = 0, w_end = 0;                      // wave-uniform: this wavefront's claimed range of camera rays
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 0);      // world ray (origin advances during the march)
-    uint32_t r_out = 0, r_sample = 0, r_meta = 0;
+    uint32_t r_sample = 0, r_meta = 0;
     // one raycast (all objects)
     uint32_t obj_i = 0;
     float g_key = 0, t_lim = INFINITY;
@@ -284,6 +329,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
     int sp = 0;
     unsigned long long c_nodes = 0, c_boxes = 0, c_tris = 0, c_march = 0;
     unsigned long long c_wnode = 0, c_wtri = 0, c_wouter = 0, c_lanes = 0, c_wtrans = 0, c_ltrans = 0, c_wuni = 0;   // wave-level step counts (SIMD efficiency)
+    uint32_t n_pushed_shadow = 0, n_pushed_chain = 0, n_overflow = 0;   // wave-uniform
 
     auto push = [&](uint32_t ref, float tmin) {
         uint2 e = make_uint2(ref, __float_as_uint(tmin));
@@ -308,10 +354,21 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
         return REF_EMPTY;
     };
 
+    // a ray from a queue entry
+    auto start_secondary = [&](const float4* e) {
+        const float4 a = e[0], b = e[1];
+        ro = f3(a.x, a.y, a.z);
+        rd = f3(a.w, b.x, b.y);
+        r_sample = __float_as_uint(b.z);
+        r_meta = __float_as_uint(b.w);
+        fl = F_FIRST;          // no raycast of this ray has finished yet; no hit of any kind
+        obj_i = 0xFFFFFFFFu;   // "before the first object"
+        t_lim = INFINITY;
+        cur = REF_EMPTY;
+        sp = 0;
+    };
+
 #ifdef TRR_PAD_VGPRS
-    // experiment: TRR_PAD_VGPRS registers kept live through the loop without a single instruction.  The register count
-    // matters even below 128 (the grid's four blocks per CU are resident either way): +8 registers +5.6 % frame time,
-    // +19 +10.8 % -- the blocks of the OTHER work set's launches share the CU only while registers are left.
     float pad_regs[TRR_PAD_VGPRS];
 #pragma unroll
     for (int k = 0; k < TRR_PAD_VGPRS; ++k) pad_regs[k] = (float)(tid + k);
@@ -321,349 +378,341 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
 #pragma unroll
         for (int k = 0; k < TRR_PAD_VGPRS; ++k) asm volatile("" : "+v"(pad_regs[k]));
 #endif
-        // ---- re-fill idle lanes -------------------------------------------------------------
-        unsigned long long idle = __ballot(cur == REF_IDLE);
-        if (idle != 0ull && !exhausted) {
-            int nidle = __popcll(idle);
+        // ---- re-fill idle lanes: first from this wavefront's own queue (secondary rays of hits it shaded), then, once
+        // that is drained, with camera rays claimed from the device-wide counter ---------------------------------------
+        const unsigned long long idle = __ballot(cur == REF_IDLE);
+        const uint32_t nq = q_tail - q_head;   // (nothing is pushed onto the own queue any more once `exhausted` spills)
+        if (idle != 0ull && (nq != 0u || !exhausted)) {
+            const int nidle = __popcll(idle);
             if (nidle >= REFILL_MIN) {
-                // work is claimed from the device counter in chunks per wavefront (one same-address atomic per chunk,
-                // not per re-fill: 10^6s of atomics on one word serialise in L2) and dealt to idle lanes from the chunk
-                if (w_next >= w_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(io.work_counter, chunk);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    w_next = min(base, total);
-                    w_end = min(base + chunk, total);
-                    if (base + chunk >= total) last_chunk = true;
-                    chunk = max(64u, min(CHUNK_MAX, (total - w_end) / (n_waves * CHUNK_DIV)));
+                const TraceArgs* ca = cold_args();
+                const FrameParams& fp = ca->fp;
+                const BatchParams& bp = ca->bp;
+                const TraceIO& io = ca->io;
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t take_q = min((uint32_t)nidle, nq);
+                if (take_q != 0u) {
+                    // entries of this queue were stored by this wavefront (other lanes): its stores have left the CU
+                    // before the loads below are issued
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const float4* my_q = io.wqueue + (size_t)wave_global * io.qcap * 2u;
+                    if (cur == REF_IDLE && rank < take_q) start_secondary(my_q + (size_t)((q_head + rank) & (io.qcap - 1u)) * 2u);
+                    q_head += take_q;
                 }
-                const uint32_t take = min((uint32_t)nidle, w_end - w_next);
-                uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                uint32_t idx = w_next + rank;
-                w_next += take;
-                if (last_chunk && w_next >= w_end) exhausted = true;
-                if (cur == REF_IDLE && rank < take) {
-                    if (RAYGEN) {
-                        uint32_t pix = idx / fp.spp, si = idx - pix * fp.spp;
-                        PixelPos pp = pixel_of(fp, bp, pix);
+                const uint32_t rest = (uint32_t)nidle - take_q;   // > 0 only when the queue has just been drained
+                if (rest != 0u && !exhausted) {
+                    // camera rays are claimed from the device counter in chunks per wavefront (one same-address atomic per
+                    // chunk, not per re-fill: 10^6s of atomics on one word serialise in L2) and dealt to idle lanes
+                    if (w_next >= w_end) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(io.work_counter, chunk);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        w_next = min(base, total);
+                        w_end = min(base + chunk, total);
+                        if (base + chunk >= total) last_chunk = true;
+                        chunk = max(chunk_min, min(CHUNK_MAX, (total - w_end) / (n_waves * CHUNK_DIV)));
+                    }
+                    const uint32_t take = min(rest, w_end - w_next);
+                    const uint32_t idx = w_next + (rank - take_q);
+                    if (from_q) {
+                        if (cur == REF_IDLE && rank >= take_q && rank - take_q < take) start_secondary(io.src_q + (size_t)idx * 2u);
+                    } else if (cur == REF_IDLE && rank >= take_q && rank - take_q < take) {
+                        const uint32_t pix = idx / fp.spp, si = idx - pix * fp.spp;
+                        const PixelPos pp = pixel_of(fp, bp, pix);
                         ro = f3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
                         rd = primary_dir(fp, pp.x, pp.y, si);
-                        r_out = idx;
-                        r_sample = pp.y * fp.width + pp.x;   // frame pixel index, used for the id buffers
-                        r_meta = idx;                        // RAYGEN: the sample index (term / nlev planes)
-                    } else {
-                        const RayRec* q = (idx < n_shadow) ? (io.shadow_q + idx) : (io.chain_q + (idx - n_shadow));
-                        float4 a = *reinterpret_cast<const float4*>(q);
-                        float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(q) + 16);
-                        ro = f3(a.x, a.y, a.z);
-                        rd = f3(a.w, b.x, b.y);
-                        r_sample = __float_as_uint(b.z);
-                        r_meta = __float_as_uint(b.w);
-                        r_out = idx - n_shadow;   // meaningful for chain rays only
+                        r_sample = idx;
+                        r_meta = 0u;           // chain ray of level 0
+                        fl = F_FIRST;
+                        obj_i = 0xFFFFFFFFu;
+                        t_lim = INFINITY;
+                        cur = REF_EMPTY;
+                        sp = 0;
                     }
-                    fl = F_FIRST;          // no raycast of this ray has finished yet; no hit of any kind
-                    obj_i = 0xFFFFFFFFu;   // "before the first object"
-                    t_lim = INFINITY;
-                    cur = REF_EMPTY;
-                    sp = 0;
+                    w_next += take;
+                    if (last_chunk && w_next >= w_end) exhausted = true;
                 }
             }
         }
-        if (__ballot(cur != REF_IDLE) == 0ull) break;
+        if (__ballot(cur != REF_IDLE) == 0ull) {
+            // every lane idle: 64 >= REFILL_MIN, so the re-fill above has run; it found nothing only if the queue is empty
+            // and the camera rays are used up -- the exit every wavefront reaches
+            if (q_tail == q_head && exhausted) break;
+            continue;
+        }
         if (COUNT) {
             if (lane == 0) c_wouter++;
             if (cur != REF_IDLE) c_lanes++;
         }
 
         // ---- transition: object finished / raycast finished / ray finished ----------------------
-#if !TRR_DEFER_END
-        if (COUNT) {
-            unsigned long long tm = __ballot(cur == REF_EMPTY);
-            if (tm != 0ull && lane == (uint32_t)__ffsll((long long)tm) - 1u) c_wtrans++;
-            if (cur == REF_EMPTY) c_ltrans++;
-        }
-#endif
-#if TRR_DEFER_END
-        // The transition block is long (winner re-evaluation, object-space ray, divisions) and costs a wavefront the same
-        // whether 1 or 64 lanes need it.  Lanes that only have to END their ray (last object done) can wait: they would
-        // sit idle until the next re-fill anyway.  The block runs when a lane needs it to go on (fresh ray, next object),
-        // when the waiting + idle lanes reach the re-fill threshold, or when no lane has traversal work left.
+        // The transition block is long (winner re-evaluation, hit set-up, object-space ray, divisions) and costs a
+        // wavefront the same whether 1 or 64 lanes need it.  Lanes that only have to END their ray (last object done) can
+        // wait: they would sit idle until the next re-fill anyway.  The block runs when a lane needs it to go on (fresh
+        // ray, next object), when the waiting + idle lanes reach the re-fill threshold, or when no lane has traversal
+        // work left.
         bool run_trans;
         {
             const bool is_empty = cur == REF_EMPTY;
-            const bool can_wait = is_empty && obj_i != 0xFFFFFFFFu && obj_i + 1u >= fp.n_objs;
+#if TRR_DEFER_END
+            const bool can_wait = is_empty && obj_i != 0xFFFFFFFFu && obj_i + 1u >= n_objs;
+#else
+            const bool can_wait = false;
+#endif
             const unsigned long long m_empty = __ballot(is_empty);
             const unsigned long long m_wait = __ballot(can_wait);
             const unsigned long long m_work = __ballot(cur < REF_IDLE);
-            run_trans = m_empty != m_wait || m_work == 0ull ||
-                        __popcll(m_wait) + __popcll(__ballot(cur == REF_IDLE)) >= REFILL_MIN;
+            run_trans = m_empty != 0ull && (m_empty != m_wait || m_work == 0ull ||
+                                            __popcll(m_wait) + __popcll(idle) >= REFILL_MIN);
         }
-        if (COUNT && run_trans) {
-            unsigned long long tm = __ballot(cur == REF_EMPTY);
-            if (tm != 0ull && lane == (uint32_t)__ffsll((long long)tm) - 1u) c_wtrans++;
-            if (cur == REF_EMPTY) c_ltrans++;
-        }
-        if (run_trans && cur == REF_EMPTY) {
-#else
-        if (cur == REF_EMPTY) {
-#endif
-            // object.rs:206-219: best candidate of the object -> world space, then mod.rs:50 ranks objects by
-            // |point_world - ray.origin| (first object wins ties: strict <, NaN greatest)
-            // With a single object there is nothing to rank: the winner of the object is the winner of the raycast.  Its
-            // barycentrics are not needed here either: a shadow ray only reports the occluder's material, and k_setup
-            // re-evaluates a chain ray's winner from (slot, ray) with full wavefronts -- the same tri_test on the same
-            // inputs, so the same bits -- instead of the few lanes that end their object in this iteration.
-            const bool rank_free = fp.n_objs == 1u;
-            if ((fl & F_OHAVE) && rank_free) {
-                fl = (fl | F_GHAVE) & ~F_OHAVE;
-                g_slot = o_slot;
-                g_obj = 0u;
+        if (run_trans) {
+            const TraceArgs* ca = cold_args();
+            const FrameParams& fp = ca->fp;
+            const BatchParams& bp = ca->bp;
+            const TraceIO& io = ca->io;
+            const uint32_t L = fp.n_lights;
+            const size_t cap = bp.cap;
+            if (COUNT) {
+                unsigned long long tm = __ballot(cur == REF_EMPTY);
+                if (tm != 0ull && lane == (uint32_t)__ffsll((long long)tm) - 1u) c_wtrans++;
+                if (cur == REF_EMPTY) c_ltrans++;
             }
-            if (fl & F_OHAVE) {
-                const ObjRec* ob = fp.objs + obj_i;
-                const float4* tp = reinterpret_cast<const float4*>(fp.tris + o_slot);
-                float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
-                TriHit h;
-                h.u = h.v = h.w = 0.0f; h.point = f3(0, 0, 0); h.key = 0.0f;
-                (void)tri_test(q0, q1, q2, q3.z, oo, od, fp.delta, h);   // same inputs as in the leaf loop -> same bits
-                F3 pw = xform_point(ob->fwd, h.point);
-                float key = norm(pw - ro);
-                bool better;
-                if (!(fl & F_GHAVE)) better = true;
-                else if (is_nan(key)) better = false;
-                else if (is_nan(g_key)) better = true;
-                else better = key < g_key;
-                if (better) {
-                    fl |= F_GHAVE; g_key = key; g_slot = o_slot; g_obj = obj_i;
-                    // later objects only need boxes nearer than this hit (ray parameter + slack)
-                    float th = sqrtf(h.key) / len_d;
-                    if (th == th) t_lim = th * (1.0f + PRUNE_REL);
+            // what the end of a chain ray leaves for the hit set-up below
+            bool final_hit = false;          // this lane's chain ray ended on a hit that is to be shaded
+            F3 h_org = f3(0, 0, 0);          // origin of the raycast that found it
+            uint32_t h_slot = 0, h_obj = 0, h_gid = 0, h_flags = 0;   // its triangle: slot, object, global id, TriRec.flags
+            int32_t h_mat = -1;
+            if (cur == REF_EMPTY) {
+                // object.rs:206-219: best candidate of the object -> world space, then mod.rs:50 ranks objects by
+                // |point_world - ray.origin| (first object wins ties: strict <, NaN greatest)
+                // With a single object there is nothing to rank: the winner of the object is the winner of the raycast.
+                const bool rank_free = n_objs == 1u;
+                if ((fl & F_OHAVE) && rank_free) {
+                    fl = (fl | F_GHAVE) & ~F_OHAVE;
+                    g_slot = o_slot;
+                    g_obj = 0u;
                 }
-                fl &= ~F_OHAVE;
-            }
-            ++obj_i;
-            if (obj_i >= fp.n_objs) {
-                // raycast done (mod.rs:45-51); raycast_transparent loop (mod.rs:100-111): only .last() is consumed,
-                // so each finished raycast with a hit overwrites the ray's result record
-                const bool is_shadow = !RAYGEN && (r_meta & 0x100u) != 0u;
-                bool again = false;
-                const bool first_cast = (fl & F_FIRST) != 0u;
-                if (fl & F_GHAVE) {
-                    const float4 q3 = reinterpret_cast<const float4*>(fp.tris + g_slot)[3];
-                    const uint32_t tri_id = __float_as_uint(q3.x);
-                    const int32_t mat = (int32_t)__float_as_uint(q3.y);
-                    const bool transp = (__float_as_uint(q3.w) & 1u) != 0u;
-                    if (is_shadow) {
-                        uint32_t level = r_meta & 0xFFu, light = r_meta >> 16;
-                        io.occ[((size_t)level * fp.n_lights + light) * bp.cap + r_sample] = mat >= 0 ? mat : -2;
-                    } else {
-                        float4* dst = reinterpret_cast<float4*>(io.hits + r_out);
-                        dst[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(g_slot));   // the origin THIS raycast used (march)
-                        dst[1] = make_float4(__uint_as_float(g_obj), __uint_as_float(tri_id), 0.0f, 0.0f);
-                        if (RAYGEN && first_cast) io.nlev[r_meta] = NLEV_PENDING;   // k_setup shades it at level 0
+                if (fl & F_OHAVE) {
+                    const ObjRec* ob = fp.objs + obj_i;
+                    const float4* tp = reinterpret_cast<const float4*>(g_tris + o_slot);
+                    float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+                    TriHit h;
+                    h.u = h.v = h.w = 0.0f; h.point = f3(0, 0, 0); h.key = 0.0f;
+                    (void)tri_test(q0, q1, q2, q3.z, oo, od, delta, h);   // same inputs as in the leaf loop -> same bits
+                    F3 pw = xform_point(ob->fwd, h.point);
+                    float key = norm(pw - ro);
+                    bool better;
+                    if (!(fl & F_GHAVE)) better = true;
+                    else if (is_nan(key)) better = false;
+                    else if (is_nan(g_key)) better = true;
+                    else better = key < g_key;
+                    if (better) {
+                        fl |= F_GHAVE; g_key = key; g_slot = o_slot; g_obj = obj_i;
+                        // later objects only need boxes nearer than this hit (ray parameter + slack)
+                        float th = sqrtf(h.key) / len_d;
+                        if (th == th) t_lim = th * (1.0f + PRUNE_REL);
                     }
-                    if (RAYGEN && first_cast && io.first_obj != nullptr) {
-                        io.first_obj[r_sample] = g_obj;
-                        io.first_tri[r_sample] = tri_id;
-                    }
-                    if (transp) {
-                        ro = ro + scale(rd, 0.05f);   // mod.rs:106
-                        again = true;
-                        if (COUNT) c_march++;
-                    }
-                } else if (first_cast) {
-                    if (is_shadow) {
-                        uint32_t level = r_meta & 0xFFu, light = r_meta >> 16;
-                        io.occ[((size_t)level * fp.n_lights + light) * bp.cap + r_sample] = -1;
-                    } else if (RAYGEN) {
-                        // mod.rs:119: a camera ray that hits nothing is skybox(ray.direction).  Only the fact is recorded
-                        // here (no hit record); k_setup<LEVEL0> evaluates the sky for these samples with full wavefronts
-                        // instead of the few lanes that end their ray in this iteration
-                        io.nlev[r_meta] = 0;
-                    } else {
-                        float4* dst = reinterpret_cast<float4*>(io.hits + r_out);
-                        dst[0] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-                        dst[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    }
-                    if (RAYGEN && io.first_obj != nullptr) {
-                        io.first_obj[r_sample] = 0xFFFFFFFFu;
-                        io.first_tri[r_sample] = 0xFFFFFFFFu;
-                    }
+                    fl &= ~F_OHAVE;
                 }
-                fl &= ~(F_FIRST | F_GHAVE);
-                if (again) {
-                    obj_i = 0;
-                    t_lim = INFINITY;
-                } else {
-                    cur = REF_IDLE;
-                }
-            }
-            if (cur != REF_IDLE) {
-                // object.rs:186-195: ray into object space (direction NOT renormalised), bvh::Ray::new
-                // normalises its own copy and keeps 1/direction [crate]
-                const ObjRec* ob = fp.objs + obj_i;
-                oo = xform_point(ob->inv, ro);
-                od = xform_vec(ob->inv, rd);
-                len_d = norm(od);
-                F3 dn = unscale(od, len_d);
-                oi = f3(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
-                slack_abs = ob->slack_abs;
-                lim_n = t_lim * len_d + slack_abs;
-                if (!(lim_n == lim_n)) lim_n = INFINITY;
-                fl = (fl & ~(F_OHAVE | F_SKIPBOX)) | ((ob->flags & 1u) ? F_SKIPBOX : 0u);
-                cur = ob->root;
-                sp = 0;
-            }
-        }
-
-        // ---- one step per iteration, chosen for the WHOLE wavefront: either every lane that stands on an inner node
-        // visits it, or every lane that stands on a leaf tests ONE of its triangles.  The kind with more waiting lanes
-        // runs (node steps weighted by NODE_BIAS/8); the other lanes keep their state for a later iteration.  A step
-        // costs the same whether 1 or 64 lanes need it, so this keeps the SIMD lanes of divergent rays busy.
-        const unsigned long long m_inner = __ballot(cur < REF_LEAF);
-        const unsigned long long m_leaf = __ballot(cur >= REF_LEAF && cur < REF_IDLE);
-        const bool node_step = m_inner != 0ull && (__popcll(m_inner) * NODE_BIAS >= __popcll(m_leaf) * 8);
-
-        if (node_step) {
-            if (cur < REF_LEAF) {
-                const float4* nd = reinterpret_cast<const float4*>(fp.nodes + cur);
-                float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
-                uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
-#ifdef TRR_DUMMY_LOAD
-                {   // experiment: one more 16-B load per lane from the node's own cache line (is the L1 / address pipe a limit?)
-                    float4 extra = nd[7];
-                    asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
-                }
-#endif
-#ifdef TRR_DUMMY_VALU
-                {   // experiment: TRR_DUMMY_VALU extra dependent vector instructions per node step (is the kernel VALU-bound?)
-                    float dv = lox.x;
-#pragma unroll
-                    for (int k = 0; k < TRR_DUMMY_VALU; ++k) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dv));
-                    asm volatile("" ::"v"(dv));
-                }
-#endif
-                if (COUNT) {
-                    c_nodes++; c_boxes += 4;
-                    const unsigned long long am = __ballot(true);
-                    const uint32_t first_lane = (uint32_t)__ffsll((long long)am) - 1u;
-                    if (lane == first_lane) c_wnode++;
-                    // node steps in which every participating lane stands on the SAME node
-                    const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-                    if (__ballot(cur == cur0) == am && lane == first_lane) c_wuni++;
-                }
-                // [crate] Ray::intersects_aabb per child, same arithmetic as the per-triangle test below, so a parent
-                // box (exact union of its children) can never reject what a triangle's own box accepts.  Written with
-                // scalars and selects only (no arrays, no short-circuit branches): keeps the step branch-free.
-                // An unused child slot holds the box (+inf .. +inf), which fails the test for every ray; a NaN tmin keeps
-                // the child (NaN > x is false) and simply does not take part in the ordering.
-#define TRR_BOX(T, R, LX, LY, LZ, HX, HY, HZ, CH)                                                          \
-    float T;                                                                                               \
-    uint32_t R;                                                                                            \
-    {                                                                                                      \
-        float ax = ((LX) - oo.x) * oi.x, bx = ((HX) - oo.x) * oi.x;                                        \
-        float ay = ((LY) - oo.y) * oi.y, by = ((HY) - oo.y) * oi.y;                                        \
-        float az = ((LZ) - oo.z) * oi.z, bz = ((HZ) - oo.z) * oi.z;                                        \
-        float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));                                 \
-        float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));                                 \
-        bool hit = (tmax > rmax(tmin, 0.0f)) & !(tmin > lim_n);                                            \
-        T = hit ? tmin : INFINITY;                                                                         \
-        R = hit ? (CH) : REF_EMPTY;                                                                        \
-    }
-                TRR_BOX(t0, r0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x)
-                TRR_BOX(t1, r1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y)
-                TRR_BOX(t2, r2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
-                TRR_BOX(t3, r3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
-#undef TRR_BOX
-                // sort the four (tmin, ref) pairs ascending: 5-comparator network of selects
-#define TRR_CSWAP(TI, RI, TJ, RJ)                                                  \
-    {                                                                              \
-        bool sw_ = TJ < TI;                                                        \
-        float ta_ = sw_ ? TJ : TI, tb_ = sw_ ? TI : TJ;                            \
-        uint32_t ra_ = sw_ ? RJ : RI, rb_ = sw_ ? RI : RJ;                         \
-        TI = ta_; TJ = tb_; RI = ra_; RJ = rb_;                                    \
-    }
-                TRR_CSWAP(t0, r0, t1, r1) TRR_CSWAP(t2, r2, t3, r3) TRR_CSWAP(t0, r0, t2, r2)
-                TRR_CSWAP(t1, r1, t3, r3) TRR_CSWAP(t1, r1, t2, r2)
-#undef TRR_CSWAP
-                // far children go on the stack, farthest first.  Fast path: three unconditional LDS stores, the stack
-                // pointer advances only past valid entries (a slot above the top may hold garbage).
-                if (sp + 3 <= STACK_LDS) {
-                    const int i3 = sp, i2 = i3 + (r3 != REF_EMPTY ? 1 : 0), i1 = i2 + (r2 != REF_EMPTY ? 1 : 0);
-                    s_stack[i3 * TRACE_THREADS + tid] = make_uint2(r3, __float_as_uint(t3));
-                    s_stack[i2 * TRACE_THREADS + tid] = make_uint2(r2, __float_as_uint(t2));
-                    s_stack[i1 * TRACE_THREADS + tid] = make_uint2(r1, __float_as_uint(t1));
-                    sp = i1 + (r1 != REF_EMPTY ? 1 : 0);
-                } else {
-                    if (r3 != REF_EMPTY) push(r3, t3);
-                    if (r2 != REF_EMPTY) push(r2, t2);
-                    if (r1 != REF_EMPTY) push(r1, t1);
-                }
-                cur = (r0 != REF_EMPTY) ? r0 : pop();
-            }
-        } else if (m_leaf != 0ull) {
-            // ---- leaf: own-box test + exact test of the leaf's next TRR_TRIS_PER_STEP remaining triangles ------------
-            if (cur >= REF_LEAF && cur < REF_IDLE) {
-                const uint32_t slot = (cur & 0x7FFFFFFFu) >> 2;
-                if (COUNT) {
-                    if (lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) c_wtri++;
-                }
-                // one triangle: triangle.rs:88-95 box (empty.grow(a).grow(b).grow(c + 1e-4)) + [crate] slab test, then the
-                // exact test; candidates are ranked by (key, triangle id), so the order of the tests does not matter
-                auto test_one = [&](uint32_t sl, float4 q0, float4 q1, float4 q2, float4 q3) {
-                    if (COUNT) c_boxes++;
-                    bool cand = true;
-                    if (!(fl & F_SKIPBOX)) {
-                        F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x);
-                        F3 c2 = f3(c.x + 0.0001f, c.y + 0.0001f, c.z + 0.0001f);
-                        F3 lo = f3(rmin(rmin(a.x, b.x), c2.x), rmin(rmin(a.y, b.y), c2.y), rmin(rmin(a.z, b.z), c2.z));
-                        F3 hi = f3(rmax(rmax(a.x, b.x), c2.x), rmax(rmax(a.y, b.y), c2.y), rmax(rmax(a.z, b.z), c2.z));
-                        float ax = (lo.x - oo.x) * oi.x, bx = (hi.x - oo.x) * oi.x;
-                        float ay = (lo.y - oo.y) * oi.y, by = (hi.y - oo.y) * oi.y;
-                        float az = (lo.z - oo.z) * oi.z, bz = (hi.z - oo.z) * oi.z;
-                        float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));
-                        float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));
-                        // the second condition: cannot beat the current best (slack keeps this conservative)
-                        cand = (tmax > rmax(tmin, 0.0f)) && !(tmin > lim_n);
-                    }
-                    if (cand) {
-                        if (COUNT) c_tris++;
-                        TriHit h;
-                        if (tri_test(q0, q1, q2, q3.z, oo, od, fp.delta, h)) {
-                            uint32_t tri_id = __float_as_uint(q3.x);
-                            if (candidate_better((fl & F_OHAVE) != 0u, h.key, tri_id, o_key, o_tri)) {
-                                fl |= F_OHAVE; o_key = h.key; o_slot = sl; o_tri = tri_id;
-                                float dist = sqrtf(h.key);
-                                if (dist == dist) lim_n = rmin(lim_n, dist * (1.0f + PRUNE_REL) + slack_abs);
+                ++obj_i;
+                if (obj_i >= n_objs) {
+                    // raycast done (mod.rs:45-51); raycast_transparent loop (mod.rs:100-111): only .last() is consumed
+                    const bool is_shadow = (r_meta & META_SHADOW) != 0u;
+                    const uint32_t level = r_meta & 0xFFu;
+                    const bool first_cast = (fl & F_FIRST) != 0u;
+                    bool again = false, final_miss = false;
+                    if (fl & F_GHAVE) {
+                        const float4 q3 = reinterpret_cast<const float4*>(g_tris + g_slot)[3];
+                        const uint32_t gid = __float_as_uint(q3.x);
+                        const int32_t mat = (int32_t)__float_as_uint(q3.y);
+                        const bool transp = (__float_as_uint(q3.w) & TRI_FLAG_TRANSPARENT) != 0u;
+                        if (r_meta == 0u && first_cast && io.first_obj != nullptr) {
+                            // id buffers: the camera ray's FIRST closest hit, per pixel (1 spp only); triangle id = row in
+                            // the object's triangle array
+                            const PixelPos pp = pixel_of(fp, bp, r_sample / fp.spp);
+                            io.first_obj[pp.y * fp.width + pp.x] = g_obj;
+                            io.first_tri[pp.y * fp.width + pp.x] = gid - fp.objs[g_obj].tri_base;
+                        }
+                        again = transp && (fl >> 16) < MARCH_CAP;
+                        if (is_shadow) {
+                            // only the last occluder of the march counts: every raycast with a hit overwrites the code
+                            io.occ[((size_t)level * L + (r_meta >> 16)) * cap + r_sample] = mat >= 0 ? mat : -2;
+                        } else if (again) {
+                            // the next raycast may find nothing, and then THIS hit is the ray's result: keep it in memory
+                            // (rare: illum 6/7 surfaces only), with the origin this raycast used
+                            float4* dst = reinterpret_cast<float4*>(io.hits + r_sample);
+                            dst[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(g_slot));
+                            dst[1] = make_float4(__uint_as_float(g_obj), __uint_as_float(gid), 0.0f, 0.0f);
+                        } else {
+                            final_hit = true;
+                            h_org = ro; h_slot = g_slot; h_obj = g_obj;
+                            h_gid = gid; h_mat = mat; h_flags = __float_as_uint(q3.w);
+                        }
+                        if (again) {
+                            ro = ro + scale(rd, 0.05f);   // mod.rs:106
+                            fl += 0x10000u;
+                            if (COUNT) c_march++;
+                        }
+                    } else if (first_cast) {
+                        if (is_shadow) io.occ[((size_t)level * L + (r_meta >> 16)) * cap + r_sample] = -1;
+                        else {
+                            final_miss = true;
+                            if (r_meta == 0u && io.first_obj != nullptr) {
+                                const PixelPos pp = pixel_of(fp, bp, r_sample / fp.spp);
+                                io.first_obj[pp.y * fp.width + pp.x] = 0xFFFFFFFFu;
+                                io.first_tri[pp.y * fp.width + pp.x] = 0xFFFFFFFFu;
                             }
                         }
+                    } else if (!is_shadow) {
+                        // the march ended on a raycast that found nothing: the previous (transparent) hit is the result
+                        const float4* src = reinterpret_cast<const float4*>(io.hits + r_sample);
+                        const float4 a = src[0], b = src[1];
+                        final_hit = true;
+                        h_org = f3(a.x, a.y, a.z); h_slot = __float_as_uint(a.w); h_obj = __float_as_uint(b.x);
+                        const float4 q3 = reinterpret_cast<const float4*>(g_tris + h_slot)[3];
+                        h_gid = __float_as_uint(q3.x); h_mat = (int32_t)__float_as_uint(q3.y); h_flags = __float_as_uint(q3.w);
                     }
-                };
-                const float4* tp = reinterpret_cast<const float4*>(fp.tris + slot);
-#if TRR_TRIS_PER_STEP >= 2
-                // both records are requested before the first is used: the second one's latency hides behind the first test
-                uint32_t sl = slot;
-                const bool two = (cur & 3u) != 0u;
-                const float4* tq = two ? tp + 4 : tp;
-                float4 a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3];
-                float4 b0 = tq[0], b1 = tq[1], b2 = tq[2], b3 = tq[3];
-                test_one(sl, a0, a1, a2, a3);
-                if (two) test_one(sl + 1u, b0, b1, b2, b3);
-                // ref = LEAF | first << 2 | count-1: two triangles consumed -> first+2, count-2
-                cur = ((cur & 3u) >= 2u) ? cur + 6u : pop();
-#else
-                test_one(slot, tp[0], tp[1], tp[2], tp[3]);
-                // next triangle of the leaf (ref = LEAF | first << 2 | count-1  ->  first+1, count-2), else pop
-                cur = (cur & 3u) ? cur + 3u : pop();
-#endif
+                    // mod.rs:125-127: with max_depth == 0 even a hit is shaded as skybox(ray.direction)
+                    if (final_hit && fp.max_depth == 0u) { final_hit = false; final_miss = true; }
+                    if (final_miss) {
+                        // mod.rs:119: no hit -> skybox(ray.direction) ends the chain; the resolve pass looks the sky up with
+                        // full wavefronts.  A camera ray that misses only records the fact (the resolve pass rebuilds its
+                        // direction from the sample index); a reflection ray that misses leaves its direction.
+                        if (level == 0u) io.nlev[r_sample] = 0;
+                        else if (fp.sky != nullptr) io.term[r_sample] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+                    }
+                    fl &= ~(F_FIRST | F_GHAVE);
+                    if (again) {
+                        obj_i = 0;
+                        t_lim = INFINITY;
+                    } else {
+                        cur = REF_IDLE;
+                    }
+                }
+                if (cur != REF_IDLE) {
+                    // object.rs:186-195: ray into object space (direction NOT renormalised), bvh::Ray::new
+                    // normalises its own copy and keeps 1/direction [crate]
+                    const ObjRec* ob = fp.objs + obj_i;
+                    oo = xform_point(ob->inv, ro);
+                    od = xform_vec(ob->inv, rd);
+                    len_d = norm(od);
+                    F3 dn = unscale(od, len_d);
+                    oi = f3(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
+                    slack_abs = ob->slack_abs;
+                    lim_n = t_lim * len_d + slack_abs;
+                    if (!(lim_n == lim_n)) lim_n = INFINITY;
+                    fl = (fl & ~(F_OHAVE | F_SKIPBOX)) | ((ob->flags & 1u) ? F_SKIPBOX : 0u);
+                    cur = ob->root;
+                    sp = 0;
+                }
+            }
+
+            // ---- hit set-up (mod.rs:124-153, 199-206; object.rs:198-219) of the chain rays that have just ended on a hit:
+            // shaded-hit record of the level, then L shadow rays and at most one reflection ray into this wavefront's queue
+            const unsigned long long hm = __ballot(final_hit);
+            if (hm != 0ull) {
+                bool spawn = false;
+                const uint32_t level = r_meta & 0xFFu;
+                F3 P = f3(0, 0, 0), N = f3(0, 0, 0);
+                if (final_hit) {
+                    // three independent loads (triangle, object, interpolation record): ONE memory round trip
+                    const ObjRec* ob = fp.objs + h_obj;
+                    const float4* tp = reinterpret_cast<const float4*>(g_tris + h_slot);
+                    const float4* ipp = reinterpret_cast<const float4*>(fp.interp + h_gid);
+                    float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                    float4 i0 = ipp[0], i1 = ipp[1], i2 = ipp[2], i3 = ipp[3];
+                    const float len = reinterpret_cast<const float*>(tp)[14];
+                    F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x);
+                    // the winner's barycentrics (triangle.rs:84) from the object-space ray of the raycast that found it
+                    // (object.rs:186-189): the same tri_test on the same inputs as in the leaf loop, so the same bits
+                    TriHit th;
+                    th.u = th.v = th.w = 0.0f; th.point = f3(0, 0, 0); th.key = 0.0f;
+                    (void)tri_test(q0, q1, q2, len, xform_point(ob->inv, h_org), xform_vec(ob->inv, rd), delta, th);
+                    const float u = th.u, v = th.v, w = th.w;
+                    F3 na = f3(i0.x, i0.y, i0.z), nb = f3(i0.w, i1.x, i1.y), nc = f3(i1.z, i1.w, i2.x);
+                    // object.rs:201-203
+                    F3 point = (scale(a, u) + scale(b, v)) + scale(c, w);
+                    F3 normal = (scale(na, u) + scale(nb, v)) + scale(nc, w);
+                    float tu = (i2.y * u + i2.w * v) + i3.y * w;
+                    float tv = (i2.z * u + i3.x * v) + i3.z * w;
+                    // object.rs:209-210 (forward matrix for the normal too)
+                    P = xform_point(ob->fwd, point);
+                    N = xform_vec(ob->fwd, normal);
+                    const bool reflective = (h_flags & TRI_FLAG_REFLECTIVE) != 0u;   // material.rs:47-49
+                    float4* lv = io.level + ((size_t)level * cap + r_sample) * LEVEL_F4;
+                    lv[0] = make_float4(P.x, P.y, P.z, N.x);
+                    lv[1] = make_float4(N.y, N.z, rd.x, rd.y);
+                    lv[2] = make_float4(rd.z, tu, tv, __int_as_float(h_mat));
+                    io.nlev[r_sample] = (uint8_t)(level + 1u);
+                    if (reflective) {
+                        if (level + 1u < fp.max_depth) spawn = true;
+                        else if (fp.sky != nullptr) {
+                            // mod.rs:125-127: the nested shade() is at max_depth -> skybox(reflection direction)
+                            F3 r2 = reflect(rd, N);
+                            io.term[r_sample] = make_float4(r2.x, r2.y, r2.z, 0.0f);
+                        }
+                    }
+                }
+                const unsigned long long sm = __ballot(spawn);
+                const uint32_t nh = (uint32_t)__popcll(hm), ns = (uint32_t)__popcll(sm);
+                const uint32_t need = nh * L + ns;
+                // destination: the wavefront's own ring, or -- once it can claim no more work items -- the spill queue of
+                // the launch (one returning atomic per wavefront and set-up)
+                const bool spill = (exhausted || io.spill_always != 0u) && io.spill_q != nullptr;
+                float4* dst = io.wqueue + (size_t)wave_global * io.qcap * 2u;
+                uint32_t base = q_tail, mask = io.qcap - 1u;
+                bool room = true;
+                if (spill) {
+                    uint32_t b0 = 0;
+                    if (lane == 0) b0 = atomicAdd(io.spill_n, need);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+                    dst = io.spill_q;
+                    mask = 0xFFFFFFFFu;
+                    room = base + need <= io.spill_cap;
+                } else {
+                    room = (q_tail - q_head) + need <= io.qcap;
+                    q_tail += need;
+                }
+                if (!room) n_overflow++;   // cannot happen (capacities are proven bounds, see api.hip); counted, never out of bounds
+                if (final_hit && room) {
+                    // shadow rays: mod.rs:149-153, one per light, grouped per light (coherent re-fills)
+                    const uint32_t rk = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+                    for (uint32_t l = 0; l < L; ++l) {
+                        const LightRec* lt = fp.lights + l;
+                        const F3 ld = normalize(f3(lt->pos[0], lt->pos[1], lt->pos[2]) - P);   // mod.rs:149
+                        const F3 o = P + scale(ld, delta);                                     // mod.rs:151
+                        float4* e = dst + (size_t)((base + l * nh + rk) & mask) * 2u;
+                        e[0] = make_float4(o.x, o.y, o.z, ld.x);
+                        e[1] = make_float4(ld.y, ld.z, __uint_as_float(r_sample), __uint_as_float(level | META_SHADOW | (l << 16)));
+                    }
+                }
+                if (spawn && room) {
+                    // reflection ray: mod.rs:203-206 (traced once per hit; the value is light-independent)
+                    const uint32_t rk = (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+                    const F3 o = P + scale(N, delta), d = reflect(rd, N);
+                    float4* e = dst + (size_t)((base + nh * L + rk) & mask) * 2u;
+                    e[0] = make_float4(o.x, o.y, o.z, d.x);
+                    e[1] = make_float4(d.y, d.z, __uint_as_float(r_sample), __uint_as_float(level + 1u));
+                }
+                n_pushed_shadow += nh * L;
+                n_pushed_chain += ns;
             }
         }
+
+#include "trace_step.inl"
     }
 
 #ifdef TRR_PAD_VGPRS
 #pragma unroll
     for (int k = 0; k < TRR_PAD_VGPRS; ++k) asm volatile("" ::"v"(pad_regs[k]));
 #endif
+    // rays this wavefront queued (the ray statistics of trr_stats) and the queue's overflow count (always 0)
+    const TraceIO& io = cold_args()->io;
+    if (lane == 0) {
+        atomicAdd(io.counters + 11, (unsigned long long)n_pushed_shadow);
+        atomicAdd(io.counters + 12, (unsigned long long)n_pushed_chain);
+        if (n_overflow) atomicAdd(io.counters + 13, (unsigned long long)n_overflow);
+    }
     if (COUNT) {
         // wave reduction, then one atomic per wavefront and counter
         for (int off = 32; off > 0; off >>= 1) {
@@ -696,44 +745,303 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Fram
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_setup: one chain ray's closest hit -> shaded-hit record + secondary rays (mod.rs:116-153, 199-206;
-// object.rs:198-219).  Queue slots are claimed with one atomic per wavefront and queue.
+// The level-synchronous schedule (big batches): specialised kernels, one launch per ray population.
+//   k_trace_level<RAYGEN>   camera rays                      -> HitRec per sample
+//   per level: k_setup      HitRec -> shaded-hit record, L shadow rays + <= 1 reflection ray into device-wide queues
+//              k_trace_level<QUEUE>  shadow rays of the level + reflection rays of the next in ONE launch
+// Every wavefront does one thing (thin ray start / end blocks, hit set-up with full wavefronts), which makes a ray cheaper
+// than in k_trace; the price is 2 * max_depth + 1 dependent launches per batch, each with a ramp-up and a tail.
 // ------------------------------------------------------------------------------------------------
+template <bool RAYGEN, bool COUNT>
+__global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_level(FrameParams fp, BatchParams bp, LevelIO io) {
+    __shared__ uint2 s_stack[STACK_LDS * TRACE_THREADS];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    uint2* my_spill = io.spill + ((size_t)blockIdx.x * TRACE_THREADS + tid) * STACK_SPILL;
+    const Node4* const g_nodes = fp.nodes;
+    const TriRec* const g_tris = fp.tris;
+    const float delta = fp.delta;
 
-DEV void store_ray(RayRec* q, F3 o, F3 d, uint32_t sample, uint32_t meta) {
-    float4* p = reinterpret_cast<float4*>(q);
-    p[0] = make_float4(o.x, o.y, o.z, d.x);
-    p[1] = make_float4(d.y, d.z, __uint_as_float(sample), __uint_as_float(meta));
+    uint32_t n_shadow = 0, total;
+    if (RAYGEN) total = bp.n_samples;
+    else {
+        n_shadow = *io.n_shadow;
+        total = n_shadow + *io.n_chain;
+    }
+
+    // a launch with little (or no) work: wavefronts beyond one per 64 items leave before touching the work counter
+    // (5120 same-address atomics cost ~40 us, which is most of an empty launch)
+    if ((blockIdx.x * (TRACE_THREADS / 64) + tid / 64) * 64u >= total) return;
+
+    // per-lane state: see k_trace
+    constexpr uint32_t F_FIRST = 1u, F_GHAVE = 2u, F_OHAVE = 4u, F_SKIPBOX = 8u;
+    constexpr uint32_t REF_IDLE = 0xFFFFFFFEu;
+    uint32_t fl = 0;
+    bool exhausted = false, last_chunk = false;          // wave-uniform
+    uint32_t w_next = 0, w_end = 0;                      // wave-uniform: this wavefront's claimed range of work items
+    const uint32_t n_waves = gridDim.x * (TRACE_THREADS / 64);
+    uint32_t chunk = max(64u, min(CHUNK_MAX, total / (n_waves * CHUNK_DIV)));
+    F3 ro = f3(0, 0, 0), rd = f3(0, 0, 0);      // world ray (origin advances during the march)
+    uint32_t r_out = 0, r_sample = 0, r_meta = 0;
+    uint32_t obj_i = 0;
+    float g_key = 0, t_lim = INFINITY;
+    uint32_t g_slot = 0, g_obj = 0;
+    F3 oo = f3(0, 0, 0), od = f3(0, 0, 0), oi = f3(0, 0, 0);
+    float len_d = 1.0f, lim_n = INFINITY, slack_abs = 0.0f;
+    float o_key = 0;
+    uint32_t o_slot = 0, o_tri = 0;
+    uint32_t cur = REF_IDLE;
+    int sp = 0;
+    unsigned long long c_nodes = 0, c_boxes = 0, c_tris = 0, c_march = 0;
+    unsigned long long c_wnode = 0, c_wtri = 0, c_wouter = 0, c_lanes = 0, c_wtrans = 0, c_ltrans = 0, c_wuni = 0;
+
+    auto push = [&](uint32_t ref, float tmin) {
+        uint2 e = make_uint2(ref, __float_as_uint(tmin));
+        if (sp < STACK_LDS) s_stack[sp * TRACE_THREADS + tid] = e;
+        else if (sp < STACK_LDS + STACK_SPILL) my_spill[sp - STACK_LDS] = e;
+        else return;   // unreachable: trr_scene_create refuses trees whose stack need exceeds TRACE_STACK_ENTRIES
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        while (sp > 0) {
+            --sp;
+            uint2 e;
+            if (sp < STACK_LDS) e = s_stack[sp * TRACE_THREADS + tid];
+            else {
+                e = my_spill[sp - STACK_LDS];
+                asm volatile("" : "+v"(e.x), "+v"(e.y));   // keeps ds_read and global_load apart (see k_trace)
+            }
+            if (!(__uint_as_float(e.y) > lim_n)) return e.x;
+        }
+        return REF_EMPTY;
+    };
+
+    for (;;) {
+        // ---- re-fill idle lanes -------------------------------------------------------------
+        unsigned long long idle = __ballot(cur == REF_IDLE);
+        if (idle != 0ull && !exhausted) {
+            int nidle = __popcll(idle);
+            if (nidle >= REFILL_MIN) {
+                if (w_next >= w_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(io.work_counter, chunk);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    w_next = min(base, total);
+                    w_end = min(base + chunk, total);
+                    if (base + chunk >= total) last_chunk = true;
+                    chunk = max(64u, min(CHUNK_MAX, (total - w_end) / (n_waves * CHUNK_DIV)));
+                }
+                const uint32_t take = min((uint32_t)nidle, w_end - w_next);
+                uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                uint32_t idx = w_next + rank;
+                w_next += take;
+                if (last_chunk && w_next >= w_end) exhausted = true;
+                if (cur == REF_IDLE && rank < take) {
+                    if (RAYGEN) {
+                        uint32_t pix = idx / fp.spp, si = idx - pix * fp.spp;
+                        PixelPos pp = pixel_of(fp, bp, pix);
+                        ro = f3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
+                        rd = primary_dir(fp, pp.x, pp.y, si);
+                        r_out = idx;
+                        r_sample = pp.y * fp.width + pp.x;   // frame pixel index, used for the id buffers
+                        r_meta = 0u;
+                    } else {
+                        const float4* q = (idx < n_shadow) ? (io.shadow_q + (size_t)idx * 2u) : (io.chain_q + (size_t)(idx - n_shadow) * 2u);
+                        float4 a = q[0], b = q[1];
+                        ro = f3(a.x, a.y, a.z);
+                        rd = f3(a.w, b.x, b.y);
+                        r_sample = __float_as_uint(b.z);
+                        r_meta = __float_as_uint(b.w);
+                        r_out = idx - n_shadow;   // meaningful for chain rays only
+                    }
+                    fl = F_FIRST;
+                    obj_i = 0xFFFFFFFFu;
+                    t_lim = INFINITY;
+                    cur = REF_EMPTY;
+                    sp = 0;
+                }
+            }
+        }
+        if (__ballot(cur != REF_IDLE) == 0ull) break;
+        if (COUNT) {
+            if (lane == 0) c_wouter++;
+            if (cur != REF_IDLE) c_lanes++;
+        }
+
+        // ---- transition: object finished / raycast finished / ray finished (deferred ends: see k_trace) ------------------
+        bool run_trans;
+        {
+            const bool is_empty = cur == REF_EMPTY;
+#if TRR_DEFER_END
+            const bool can_wait = is_empty && obj_i != 0xFFFFFFFFu && obj_i + 1u >= fp.n_objs;
+#else
+            const bool can_wait = false;
+#endif
+            const unsigned long long m_empty = __ballot(is_empty);
+            const unsigned long long m_wait = __ballot(can_wait);
+            const unsigned long long m_work = __ballot(cur < REF_IDLE);
+            run_trans = m_empty != m_wait || m_work == 0ull || __popcll(m_wait) + __popcll(__ballot(cur == REF_IDLE)) >= REFILL_MIN;
+        }
+        if (COUNT && run_trans) {
+            unsigned long long tm = __ballot(cur == REF_EMPTY);
+            if (tm != 0ull && lane == (uint32_t)__ffsll((long long)tm) - 1u) c_wtrans++;
+            if (cur == REF_EMPTY) c_ltrans++;
+        }
+        if (run_trans && cur == REF_EMPTY) {
+            // object.rs:206-219 / mod.rs:50: see k_trace.  With one object the object's winner is the raycast's winner.
+            const bool rank_free = fp.n_objs == 1u;
+            if ((fl & F_OHAVE) && rank_free) {
+                fl = (fl | F_GHAVE) & ~F_OHAVE;
+                g_slot = o_slot;
+                g_obj = 0u;
+            }
+            if (fl & F_OHAVE) {
+                const ObjRec* ob = fp.objs + obj_i;
+                const float4* tp = reinterpret_cast<const float4*>(fp.tris + o_slot);
+                float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+                TriHit h;
+                h.u = h.v = h.w = 0.0f; h.point = f3(0, 0, 0); h.key = 0.0f;
+                (void)tri_test(q0, q1, q2, q3.z, oo, od, fp.delta, h);   // same inputs as in the leaf loop -> same bits
+                F3 pw = xform_point(ob->fwd, h.point);
+                float key = norm(pw - ro);
+                bool better;
+                if (!(fl & F_GHAVE)) better = true;
+                else if (is_nan(key)) better = false;
+                else if (is_nan(g_key)) better = true;
+                else better = key < g_key;
+                if (better) {
+                    fl |= F_GHAVE; g_key = key; g_slot = o_slot; g_obj = obj_i;
+                    float th = sqrtf(h.key) / len_d;
+                    if (th == th) t_lim = th * (1.0f + PRUNE_REL);
+                }
+                fl &= ~F_OHAVE;
+            }
+            ++obj_i;
+            if (obj_i >= fp.n_objs) {
+                // raycast done (mod.rs:45-51); raycast_transparent loop (mod.rs:100-111): only .last() is consumed,
+                // so each finished raycast with a hit overwrites the ray's result record
+                const bool is_shadow = !RAYGEN && (r_meta & META_SHADOW) != 0u;
+                bool again = false;
+                const bool first_cast = (fl & F_FIRST) != 0u;
+                if (fl & F_GHAVE) {
+                    const float4 q3 = reinterpret_cast<const float4*>(fp.tris + g_slot)[3];
+                    const uint32_t gid = __float_as_uint(q3.x);
+                    const int32_t mat = (int32_t)__float_as_uint(q3.y);
+                    const bool transp = (__float_as_uint(q3.w) & TRI_FLAG_TRANSPARENT) != 0u;
+                    if (is_shadow) {
+                        uint32_t level = r_meta & 0xFFu, light = r_meta >> 16;
+                        io.occ[((size_t)level * fp.n_lights + light) * bp.cap + r_sample] = mat >= 0 ? mat : -2;
+                    } else {
+                        float4* dst = reinterpret_cast<float4*>(io.hits + r_out);
+                        dst[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(g_slot));   // the origin THIS raycast used (march)
+                        dst[1] = make_float4(__uint_as_float(g_obj), __uint_as_float(gid), __uint_as_float((uint32_t)mat), q3.w);
+                        if (RAYGEN && first_cast) io.nlev[r_out] = NLEV_PENDING;   // k_setup shades it at level 0
+                    }
+                    if (RAYGEN && first_cast && io.first_obj != nullptr) {
+                        io.first_obj[r_sample] = g_obj;
+                        io.first_tri[r_sample] = gid - fp.objs[g_obj].tri_base;
+                    }
+                    if (transp && (fl >> 16) < MARCH_CAP) {
+                        ro = ro + scale(rd, 0.05f);   // mod.rs:106
+                        fl += 0x10000u;
+                        again = true;
+                        if (COUNT) c_march++;
+                    }
+                } else if (first_cast) {
+                    if (is_shadow) {
+                        uint32_t level = r_meta & 0xFFu, light = r_meta >> 16;
+                        io.occ[((size_t)level * fp.n_lights + light) * bp.cap + r_sample] = -1;
+                    } else if (RAYGEN) {
+                        // mod.rs:119: a camera ray that hits nothing is skybox(ray.direction).  Only the fact is recorded (one
+                        // byte, no hit record); the resolve pass evaluates the sky with full wavefronts
+                        io.nlev[r_out] = 0;
+                    } else {
+                        // a reflection ray that hits nothing: k_setup leaves its direction for the resolve pass
+                        reinterpret_cast<float4*>(io.hits + r_out)[0] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                    }
+                    if (RAYGEN && io.first_obj != nullptr) {
+                        io.first_obj[r_sample] = 0xFFFFFFFFu;
+                        io.first_tri[r_sample] = 0xFFFFFFFFu;
+                    }
+                }
+                fl &= ~(F_FIRST | F_GHAVE);
+                if (again) {
+                    obj_i = 0;
+                    t_lim = INFINITY;
+                } else {
+                    cur = REF_IDLE;
+                }
+            }
+            if (cur != REF_IDLE) {
+                // object.rs:186-195: ray into object space (direction NOT renormalised), bvh::Ray::new
+                // normalises its own copy and keeps 1/direction [crate]
+                const ObjRec* ob = fp.objs + obj_i;
+                oo = xform_point(ob->inv, ro);
+                od = xform_vec(ob->inv, rd);
+                len_d = norm(od);
+                F3 dn = unscale(od, len_d);
+                oi = f3(1.0f / dn.x, 1.0f / dn.y, 1.0f / dn.z);
+                slack_abs = ob->slack_abs;
+                lim_n = t_lim * len_d + slack_abs;
+                if (!(lim_n == lim_n)) lim_n = INFINITY;
+                fl = (fl & ~(F_OHAVE | F_SKIPBOX)) | ((ob->flags & 1u) ? F_SKIPBOX : 0u);
+                cur = ob->root;
+                sp = 0;
+            }
+        }
+
+#include "trace_step.inl"
+    }
+
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) {
+            c_nodes += __shfl_down(c_nodes, off);
+            c_boxes += __shfl_down(c_boxes, off);
+            c_tris += __shfl_down(c_tris, off);
+            c_march += __shfl_down(c_march, off);
+            c_wnode += __shfl_down(c_wnode, off);
+            c_wtri += __shfl_down(c_wtri, off);
+            c_wouter += __shfl_down(c_wouter, off);
+            c_lanes += __shfl_down(c_lanes, off);
+            c_wtrans += __shfl_down(c_wtrans, off);
+            c_ltrans += __shfl_down(c_ltrans, off);
+            c_wuni += __shfl_down(c_wuni, off);
+        }
+        if (lane == 0) {
+            atomicAdd(io.counters + KC_NODES, c_nodes);
+            atomicAdd(io.counters + KC_BOXES, c_boxes);
+            atomicAdd(io.counters + KC_TRIS, c_tris);
+            atomicAdd(io.counters + KC_MARCH, c_march);
+            atomicAdd(io.counters + KC_WNODE, c_wnode);
+            atomicAdd(io.counters + KC_WTRI, c_wtri);
+            atomicAdd(io.counters + KC_WOUTER, c_wouter);
+            atomicAdd(io.counters + KC_WLANES, c_lanes);
+            atomicAdd(io.counters + KC_WTRANS, c_wtrans);
+            atomicAdd(io.counters + KC_LTRANS, c_ltrans);
+            atomicAdd(io.counters + KC_WUNI, c_wuni);
+        }
+    }
 }
 
+// k_setup: one chain ray's closest hit -> shaded-hit record + secondary rays (mod.rs:116-153, 199-206; object.rs:198-219)
+// with full wavefronts.  Queue slots are claimed with one atomic per wavefront and queue.
 template <bool LEVEL0>
 __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, SetupIO io, uint32_t lvl) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = LEVEL0 ? bp.n_samples : *io.n_chain_in;
     const uint32_t L = fp.n_lights;
-    const uint32_t cap = bp.cap;
+    const size_t cap = bp.cap;
     // whole wavefronts iterate together (the ballots below need every lane present)
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounds = (total + stride - 1) / stride;
+    uint32_t n_sh = 0, n_ch = 0;   // wave-uniform: rays queued by this wavefront
     for (uint32_t it = 0; it < rounds; ++it) {
         uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         bool valid = i < total;
-        bool hit = false, reflective = false, spawn = false;
+        bool hit = false, spawn = false;
         F3 P = f3(0, 0, 0), N = f3(0, 0, 0), D = f3(0, 0, 0);
         uint32_t sample = 0;
-        if (LEVEL0 && valid && io.nlev[i] != NLEV_PENDING) {
-            // a camera ray that missed everything (k_trace<RAYGEN> left nlev == 0): mod.rs:119, skybox(ray.direction)
-            F3 c = f3(fp.sky_color[0], fp.sky_color[1], fp.sky_color[2]);
-            if (fp.sky != nullptr) {   // (a constant sky needs no direction)
-                uint32_t pix = i / fp.spp, si = i - pix * fp.spp;
-                PixelPos pp = pixel_of(fp, bp, pix);
-                c = skybox(fp, primary_dir(fp, pp.x, pp.y, si));
-            }
-            io.term[0 * (size_t)cap + i] = c.x;
-            io.term[1 * (size_t)cap + i] = c.y;
-            io.term[2 * (size_t)cap + i] = c.z;
-            valid = false;
-        }
+        if (LEVEL0 && valid && io.nlev[i] != NLEV_PENDING) valid = false;   // a camera ray that missed: nothing to set up
         if (valid) {
             if (LEVEL0) {
                 sample = i;
@@ -741,37 +1049,35 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
                 PixelPos pp = pixel_of(fp, bp, pix);
                 D = primary_dir(fp, pp.x, pp.y, si);
             } else {
-                const float4* q = reinterpret_cast<const float4*>(io.chain_in + i);
+                const float4* q = io.chain_in + (size_t)i * 2u;
                 float4 a = q[0], b = q[1];
                 D = f3(a.w, b.x, b.y);
                 sample = __float_as_uint(b.z);
             }
             const float4* hp = reinterpret_cast<const float4*>(io.hits + i);
-            float4 h0 = hp[0], h1 = hp[1];
+            float4 h0 = hp[0];
             uint32_t slot = __float_as_uint(h0.w);
             if (slot == 0xFFFFFFFFu || fp.max_depth == 0u) {
                 // mod.rs:119: no hit -> skybox(ray.direction) ends the chain; mod.rs:125-127: with max_depth == 0
-                // even a hit is shaded as skybox(ray.direction)
-                F3 c = skybox(fp, D);
-                io.term[0 * (size_t)cap + sample] = c.x;
-                io.term[1 * (size_t)cap + sample] = c.y;
-                io.term[2 * (size_t)cap + sample] = c.z;
-                io.nlev[sample] = (uint8_t)lvl;
+                // even a hit is shaded as skybox(ray.direction).  The resolve pass looks the sky up.
+                if (LEVEL0) io.nlev[sample] = 0;
+                else if (fp.sky != nullptr) io.term[sample] = make_float4(D.x, D.y, D.z, 0.0f);
             } else {
                 hit = true;
+                float4 h1 = hp[1];
                 const ObjRec* ob = fp.objs + __float_as_uint(h1.x);
                 const float4* tp = reinterpret_cast<const float4*>(fp.tris + slot);
-                float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+                const float4* ipp = reinterpret_cast<const float4*>(fp.interp + __float_as_uint(h1.y));
+                float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                const float len = reinterpret_cast<const float*>(tp)[14];
+                float4 i0 = ipp[0], i1 = ipp[1], i2 = ipp[2], i3 = ipp[3];
                 F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x);
                 // the winner's barycentrics (triangle.rs:84): the trace kernel kept only the slot and the origin its
-                // last raycast used; object-space ray and exact test are the ones of k_trace (object.rs:186-189)
+                // last raycast used; object-space ray and exact test are the ones of the trace kernel (object.rs:186-189)
                 TriHit th;
                 th.u = th.v = th.w = 0.0f; th.point = f3(0, 0, 0); th.key = 0.0f;
-                (void)tri_test(q0, q1, q2, q3.z, xform_point(ob->inv, f3(h0.x, h0.y, h0.z)), xform_vec(ob->inv, D), fp.delta, th);
+                (void)tri_test(q0, q1, q2, len, xform_point(ob->inv, f3(h0.x, h0.y, h0.z)), xform_vec(ob->inv, D), fp.delta, th);
                 const float u = th.u, v = th.v, w = th.w;
-                const InterpRec* ip = fp.interp + ob->tri_base + __float_as_uint(q3.x);
-                const float4* ipp = reinterpret_cast<const float4*>(ip);
-                float4 i0 = ipp[0], i1 = ipp[1], i2 = ipp[2], i3 = ipp[3];
                 F3 na = f3(i0.x, i0.y, i0.z), nb = f3(i0.w, i1.x, i1.y), nc = f3(i1.z, i1.w, i2.x);
                 // object.rs:201-203
                 F3 point = (scale(a, u) + scale(b, v)) + scale(c, w);
@@ -781,30 +1087,18 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
                 // object.rs:209-210 (forward matrix for the normal too)
                 P = xform_point(ob->fwd, point);
                 N = xform_vec(ob->fwd, normal);
-                int32_t mat = (int32_t)__float_as_uint(q3.y);
-                // mod.rs:129-134
-                F3 diff = f3(0.9f, 0.9f, 0.9f);
-                if (mat >= 0) {
-                    const MatRec* m = fp.mats + mat;
-                    if (m->tex >= 0) diff = texture_lookup(fp, m->tex, tu, tv);
-                    else if (m->flags & 1u) diff = f3(m->kd[0], m->kd[1], m->kd[2]);
-                    reflective = (m->illum == 3 || m->illum == 4);   // material.rs:47-49
-                }
-                float* lv = io.level + (size_t)lvl * LEVEL_PLANES * cap + sample;
-                lv[0 * (size_t)cap] = P.x; lv[1 * (size_t)cap] = P.y; lv[2 * (size_t)cap] = P.z;
-                lv[3 * (size_t)cap] = N.x; lv[4 * (size_t)cap] = N.y; lv[5 * (size_t)cap] = N.z;
-                lv[6 * (size_t)cap] = D.x; lv[7 * (size_t)cap] = D.y; lv[8 * (size_t)cap] = D.z;
-                lv[9 * (size_t)cap] = diff.x; lv[10 * (size_t)cap] = diff.y; lv[11 * (size_t)cap] = diff.z;
-                lv[12 * (size_t)cap] = __int_as_float(mat);
-                io.nlev[sample] = (uint8_t)(lvl + 1);
+                const bool reflective = (__float_as_uint(h1.w) & TRI_FLAG_REFLECTIVE) != 0u;   // material.rs:47-49
+                float4* lv = io.level + ((size_t)lvl * cap + sample) * LEVEL_F4;
+                lv[0] = make_float4(P.x, P.y, P.z, N.x);
+                lv[1] = make_float4(N.y, N.z, D.x, D.y);
+                lv[2] = make_float4(D.z, tu, tv, h1.z);
+                io.nlev[sample] = (uint8_t)(lvl + 1u);
                 if (reflective) {
                     if (lvl + 1 < fp.max_depth) spawn = true;
-                    else {
+                    else if (fp.sky != nullptr) {
                         // mod.rs:125-127: the nested shade() is at max_depth -> skybox(reflection direction)
-                        F3 c2 = skybox(fp, reflect(D, N));
-                        io.term[0 * (size_t)cap + sample] = c2.x;
-                        io.term[1 * (size_t)cap + sample] = c2.y;
-                        io.term[2 * (size_t)cap + sample] = c2.z;
+                        F3 r2 = reflect(D, N);
+                        io.term[sample] = make_float4(r2.x, r2.y, r2.z, 0.0f);
                     }
                 }
             }
@@ -816,13 +1110,16 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(io.n_shadow_out, nh * L);
             base = __shfl(base, 0);
+            n_sh += nh * L;
             uint32_t rank = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
             if (hit) {
                 for (uint32_t l = 0; l < L; ++l) {
                     const LightRec* lt = fp.lights + l;
                     F3 ld = normalize(f3(lt->pos[0], lt->pos[1], lt->pos[2]) - P);   // mod.rs:149
-                    store_ray(io.shadow_out + base + l * nh + rank, P + scale(ld, fp.delta), ld, sample,
-                              lvl | 0x100u | (l << 16));
+                    F3 o = P + scale(ld, fp.delta);                                  // mod.rs:151
+                    float4* e = io.shadow_out + (size_t)(base + l * nh + rank) * 2u;
+                    e[0] = make_float4(o.x, o.y, o.z, ld.x);
+                    e[1] = make_float4(ld.y, ld.z, __uint_as_float(sample), __uint_as_float(lvl | META_SHADOW | (l << 16)));
                 }
             }
         }
@@ -833,9 +1130,19 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(io.n_chain_out, ns);
             base = __shfl(base, 0);
+            n_ch += ns;
             uint32_t rank = (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
-            if (spawn) store_ray(io.chain_out + base + rank, P + scale(N, fp.delta), reflect(D, N), sample, lvl + 1);
+            if (spawn) {
+                F3 o = P + scale(N, fp.delta), d = reflect(D, N);
+                float4* e = io.chain_out + (size_t)(base + rank) * 2u;
+                e[0] = make_float4(o.x, o.y, o.z, d.x);
+                e[1] = make_float4(d.y, d.z, __uint_as_float(sample), __uint_as_float(lvl + 1u));
+            }
         }
+    }
+    if (lane == 0 && (n_sh | n_ch) != 0u) {   // the ray statistics of trr_stats
+        atomicAdd(io.counters + KC_SHADOW_RAYS, (unsigned long long)n_sh);
+        atomicAdd(io.counters + KC_CHAIN_RAYS, (unsigned long long)n_ch);
     }
 }
 
@@ -851,36 +1158,50 @@ DEV uint8_t quantize(float c) {   // render.rs:136-138: (c * 255.0) as u8
     return (uint8_t)v;
 }
 
-// Pass 1, one thread per SAMPLE: samples that hit something (nlev > 0) are evaluated deepest level first and their
-// colour replaces the terminal colour in `term`; misses (nlev == 0) already hold skybox(direction) there.
+// Pass 1, one thread per SAMPLE.  The trace / set-up kernels left, per sample: nlev = the number of shaded levels (0 = the
+// camera ray missed), a 48-byte record per shaded level (P, N, D, texture u v, material), the occluder code of every (level,
+// light) and -- where a reflective chain ends on an image sky (mod.rs:119, 125-127) -- the direction of that look-up in
+// `term`.  Levels are evaluated deepest first; the sample's colour goes to the `color` planes.
 __global__ void __launch_bounds__(256) k_resolve_samples(FrameParams fp, BatchParams bp, ResolveIO io) {
     const uint32_t L = fp.n_lights;
     const size_t cap = bp.cap;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < bp.n_samples; s += gridDim.x * blockDim.x) {
         const int n = io.nlev[s];
-        if (n == 0) continue;
-        F3 R = f3(0.0f, 0.0f, 0.0f);
-        {
+        F3 R = f3(fp.sky_color[0], fp.sky_color[1], fp.sky_color[2]);
+        if (n == 0) {
+            // mod.rs:119: the camera ray missed -> skybox(ray.direction), the direction rebuilt from the sample index
+            if (fp.sky != nullptr) {
+                const uint32_t pix = s / fp.spp, si = s - pix * fp.spp;
+                const PixelPos pp = pixel_of(fp, bp, pix);
+                R = skybox(fp, primary_dir(fp, pp.x, pp.y, si));
+            }
+        } else {
             bool need_term = false;
-            int32_t dm = __float_as_int(io.level[((size_t)(n - 1) * LEVEL_PLANES + 12) * cap + s]);
+            int32_t dm = __float_as_int(io.level[((size_t)(n - 1) * cap + s) * LEVEL_F4 + 2].w);
             if (dm >= 0) {
                 int il = fp.mats[dm].illum;
                 need_term = (il == 3 || il == 4);
             }
-            if (need_term) R = f3(io.term[s], io.term[cap + s], io.term[2 * cap + s]);
+            if (!need_term) R = f3(0.0f, 0.0f, 0.0f);
+            else if (fp.sky != nullptr) {
+                const float4 tr = io.term[s];
+                R = skybox(fp, f3(tr.x, tr.y, tr.z));
+            }
         }
         for (int k = n - 1; k >= 0; --k) {
-            const float* lv = io.level + (size_t)k * LEVEL_PLANES * cap + s;
-            F3 P = f3(lv[0], lv[cap], lv[2 * cap]);
-            F3 N = f3(lv[3 * cap], lv[4 * cap], lv[5 * cap]);
-            F3 D = f3(lv[6 * cap], lv[7 * cap], lv[8 * cap]);
-            F3 diff = f3(lv[9 * cap], lv[10 * cap], lv[11 * cap]);
-            int32_t mat = __float_as_int(lv[12 * cap]);
+            const float4* lv = io.level + ((size_t)k * cap + s) * LEVEL_F4;
+            const float4 l0 = lv[0], l1 = lv[1], l2 = lv[2];
+            F3 P = f3(l0.x, l0.y, l0.z), N = f3(l0.w, l1.x, l1.y), D = f3(l1.z, l1.w, l2.x);
+            const float tu = l2.y, tv = l2.z;
+            int32_t mat = __float_as_int(l2.w);
+            F3 diff = f3(0.9f, 0.9f, 0.9f);   // mod.rs:129-134
             F3 spec = f3(0.9f, 0.9f, 0.9f);   // mod.rs:136-139
             bool specular = false, reflective = false;
             float ns = 1.0f;
             if (mat >= 0) {
                 const MatRec* m = fp.mats + mat;
+                if (m->tex >= 0) diff = texture_lookup(fp, m->tex, tu, tv);
+                else if (m->flags & 1u) diff = f3(m->kd[0], m->kd[1], m->kd[2]);
                 if (m->flags & 2u) spec = f3(m->ks[0], m->ks[1], m->ks[2]);
                 if (m->flags & 4u) ns = m->ns;
                 specular = (m->illum == 2);
@@ -918,9 +1239,9 @@ __global__ void __launch_bounds__(256) k_resolve_samples(FrameParams fp, BatchPa
             }
             R = c;
         }
-        io.term_out[s] = R.x;
-        io.term_out[cap + s] = R.y;
-        io.term_out[2 * cap + s] = R.z;
+        io.color[s] = R.x;
+        io.color[cap + s] = R.y;
+        io.color[2 * cap + s] = R.z;
     }
 }
 
@@ -941,7 +1262,7 @@ __global__ void __launch_bounds__(256) k_resolve_pixels(FrameParams fp, BatchPar
             uint32_t s = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
             bool valid = s < bp.n_samples;   // n_samples is a multiple of spp: a group is valid or invalid as a whole
             F3 v = f3(0.0f, 0.0f, 0.0f);
-            if (valid) v = f3(io.term[s], io.term[cap + s], io.term[2 * cap + s]);
+            if (valid) v = f3(io.color[s], io.color[cap + s], io.color[2 * cap + s]);
             F3 sum = f3(0.0f, 0.0f, 0.0f);
             for (uint32_t j = 0; j < spp; ++j) {
                 F3 c = f3(__shfl(v.x, (int)(base + j)), __shfl(v.y, (int)(base + j)), __shfl(v.z, (int)(base + j)));
@@ -963,7 +1284,7 @@ __global__ void __launch_bounds__(256) k_resolve_pixels(FrameParams fp, BatchPar
         F3 color = f3(0.0f, 0.0f, 0.0f);
         for (uint32_t si = 0; si < spp; ++si) {
             uint32_t s = pix * spp + si;
-            color = f3(io.term[s], io.term[cap + s], io.term[2 * cap + s]);
+            color = f3(io.color[s], io.color[cap + s], io.color[2 * cap + s]);
             sum = sum + color;
         }
         if (fp.aa) color = unscale(sum, (float)spp);   // mod.rs:248-249
@@ -999,28 +1320,45 @@ __global__ void __launch_bounds__(256) k_assemble(uint32_t width, uint32_t heigh
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (used by render.cpp)
 // ------------------------------------------------------------------------------------------------
-int trace_blocks_per_cu(bool raygen, bool count) {
+int trace_blocks_per_cu(bool count) {
     int nb = 0;
-    hipError_t e;
-    if (raygen) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<true, true>, TRACE_THREADS, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<true, false>, TRACE_THREADS, 0);
-    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<false, true>, TRACE_THREADS, 0)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<false, false>, TRACE_THREADS, 0);
+    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<true>, TRACE_THREADS, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<false>, TRACE_THREADS, 0);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
 size_t trace_spill_bytes(uint32_t grid) { return (size_t)grid * TRACE_THREADS * STACK_SPILL * sizeof(uint2); }
+size_t trace_queue_bytes(uint32_t grid, uint32_t qcap) { return (size_t)grid * (TRACE_THREADS / 64) * qcap * 32; }
 
-void launch_trace(bool raygen, bool count, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
-                  const TraceIO& io) {
+void launch_trace(bool count, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp, const TraceIO& io) {
+    dim3 g(grid), b(TRACE_THREADS);
+    TraceArgs a;
+    a.fp = fp; a.bp = bp; a.io = io;
+    if (count) hipLaunchKernelGGL((k_trace<true>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((k_trace<false>), g, b, 0, st, a);
+}
+
+int level_blocks_per_cu(bool raygen, bool count) {
+    int nb = 0;
+    hipError_t e;
+    if (raygen) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<true, true>, TRACE_THREADS, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<true, false>, TRACE_THREADS, 0);
+    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<false, true>, TRACE_THREADS, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<false, false>, TRACE_THREADS, 0);
+    if (e != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
+void launch_trace_level(bool raygen, bool count, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
+                        const LevelIO& io) {
     dim3 g(grid), b(TRACE_THREADS);
     if (raygen) {
-        if (count) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, st, fp, bp, io);
-        else hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, st, fp, bp, io);
+        if (count) hipLaunchKernelGGL((k_trace_level<true, true>), g, b, 0, st, fp, bp, io);
+        else hipLaunchKernelGGL((k_trace_level<true, false>), g, b, 0, st, fp, bp, io);
     } else {
-        if (count) hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, st, fp, bp, io);
-        else hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, st, fp, bp, io);
+        if (count) hipLaunchKernelGGL((k_trace_level<false, true>), g, b, 0, st, fp, bp, io);
+        else hipLaunchKernelGGL((k_trace_level<false, false>), g, b, 0, st, fp, bp, io);
     }
 }
 

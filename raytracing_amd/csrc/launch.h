@@ -7,44 +7,70 @@
 namespace trr {
 
 struct TraceIO {
-    const RayRec* shadow_q;
-    const RayRec* chain_q;
+    uint32_t* work_counter;       // camera rays claimed so far (zeroed per batch)
+    HitRec* hits;                 // [cap] the transparency march's "last hit so far" (written only for illum 6/7 surfaces)
+    float4* level;                // [max_depth][cap][LEVEL_F4] shaded-hit records (48 B each)
+    float4* term;                 // [cap] xyz = direction whose skybox() value ends a reflective chain (image sky only)
+    uint8_t* nlev;                // [cap] shaded levels of the sample, 0 = the camera ray missed
+    int32_t* occ;                 // [max_depth][n_lights][cap] occluder code: material id, -1 none, -2 material None
+    float4* wqueue;               // [wavefronts of the grid][qcap][2] wave-local ray queues (32-B entries)
+    uint32_t qcap;                // power of two >= 64 * (n_lights + 1)
+    const float4* src_q;          // nullptr: the work items are the batch's camera rays; else queue entries spilled by the launch before
+    const uint32_t* src_n;        // number of entries in src_q (device memory, written by the launch before)
+    uint32_t src_cap;
+    float4* spill_q;              // nullable: where a wavefront pushes once it can claim no more work items
+    uint32_t* spill_n;
+    uint32_t spill_cap;
+    uint32_t chunk_min;           // smallest claim of work items per wavefront (>= 1)
+    uint32_t spill_always;        // 1: every push goes to the spill queue (level-synchronous schedule: one launch per level)
+    uint32_t* first_obj;          // nullable: id buffers of the camera rays' first closest hits
+    uint32_t* first_tri;
+    unsigned long long* counters; // kernel counters (device_types.h: KC_*)
+    uint2* spill;                 // traversal-stack spill, per thread of the grid
+};
+// the level-synchronous schedule's kernels
+struct LevelIO {
+    const float4* shadow_q;       // QUEUE: 32-B ray records of the level's shadow rays ...
+    const float4* chain_q;        // ... and of the next level's reflection rays
     const uint32_t* n_shadow;
     const uint32_t* n_chain;
     uint32_t* work_counter;
-    HitRec* hits;
+    HitRec* hits;                 // closest hit per chain ray, by queue position (camera rays: by sample)
+    uint8_t* nlev;                // RAYGEN: 0 = the camera ray missed, 0xFF = hit, to be shaded by k_setup
     int32_t* occ;
     uint32_t* first_obj;
     uint32_t* first_tri;
     unsigned long long* counters;
     uint2* spill;
-    float* term;      // RAYGEN: terminal colour planes (a camera ray that misses is finished by the trace kernel)
-    uint8_t* nlev;    // RAYGEN: 0 = miss (done), 0xFF = hit, to be shaded by k_setup
 };
 struct SetupIO {
-    const RayRec* chain_in;
+    const float4* chain_in;
     const uint32_t* n_chain_in;
     const HitRec* hits;
-    float* level;
-    float* term;
+    float4* level;
+    float4* term;
     uint8_t* nlev;
-    RayRec* shadow_out;
+    float4* shadow_out;
     uint32_t* n_shadow_out;
-    RayRec* chain_out;
+    float4* chain_out;
     uint32_t* n_chain_out;
+    unsigned long long* counters;
 };
 struct ResolveIO {
-    const float* level;
-    const float* term;
-    float* term_out;   // same planes as term: k_resolve_samples replaces a hit sample's terminal colour by its colour
+    const float4* level;
+    const float4* term;
     const uint8_t* nlev;
+    float* color;      // [3][cap] planes: the samples' colours, between the two resolve passes
     const int32_t* occ;
     uint8_t* strip;
 };
-int trace_blocks_per_cu(bool raygen, bool count);
+int trace_blocks_per_cu(bool count);
 size_t trace_spill_bytes(uint32_t grid);
-void launch_trace(bool raygen, bool count, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
-                  const TraceIO& io);
+size_t trace_queue_bytes(uint32_t grid, uint32_t qcap);
+void launch_trace(bool count, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp, const TraceIO& io);
+int level_blocks_per_cu(bool raygen, bool count);
+void launch_trace_level(bool raygen, bool count, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
+                        const LevelIO& io);
 void launch_setup(bool level0, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp, const SetupIO& io,
                   uint32_t lvl);
 void launch_resolve(uint32_t grid_samples, uint32_t grid_pixels, hipStream_t st, const FrameParams& fp, const BatchParams& bp,

@@ -1,0 +1,145 @@
+// trace_step.inl -- ONE traversal step of a wavefront, included textually in the loop of both trace kernels (k_trace and
+// k_trace_level in kernels.hip), which declare the state it works on: cur, sp, fl, oo, od, oi, lim_n, slack_abs, o_key,
+// o_slot, o_tri (per lane), tid, lane, s_stack, push / pop, g_nodes, g_tris, delta, the c_* counters and the F_* flag bits.
+        // ---- one step per iteration, chosen for the WHOLE wavefront: either every lane that stands on an inner node
+        // visits it, or every lane that stands on a leaf tests ONE of its triangles.  The kind with more waiting lanes
+        // runs (node steps weighted by NODE_BIAS/8); the other lanes keep their state for a later iteration.  A step
+        // costs the same whether 1 or 64 lanes need it, so this keeps the SIMD lanes of divergent rays busy.
+        const unsigned long long m_inner = __ballot(cur < REF_LEAF);
+        const unsigned long long m_leaf = __ballot(cur >= REF_LEAF && cur < REF_IDLE);
+        const bool node_step = m_inner != 0ull && (__popcll(m_inner) * NODE_BIAS >= __popcll(m_leaf) * 8);
+
+        if (node_step) {
+            if (cur < REF_LEAF) {
+                const float4* nd = reinterpret_cast<const float4*>(g_nodes + cur);
+                float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
+                uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
+#ifdef TRR_DUMMY_LOAD
+                {   // experiment: one more 16-B load per lane from the node's own cache line (is the L1 / address pipe a limit?)
+                    float4 extra = nd[7];
+                    asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
+                }
+#endif
+#ifdef TRR_DUMMY_VALU
+                {   // experiment: TRR_DUMMY_VALU extra dependent vector instructions per node step (is the kernel VALU-bound?)
+                    float dv = lox.x;
+#pragma unroll
+                    for (int k = 0; k < TRR_DUMMY_VALU; ++k) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dv));
+                    asm volatile("" ::"v"(dv));
+                }
+#endif
+                if (COUNT) {
+                    c_nodes++; c_boxes += 4;
+                    const unsigned long long am = __ballot(true);
+                    const uint32_t first_lane = (uint32_t)__ffsll((long long)am) - 1u;
+                    if (lane == first_lane) c_wnode++;
+                    // node steps in which every participating lane stands on the SAME node
+                    const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                    if (__ballot(cur == cur0) == am && lane == first_lane) c_wuni++;
+                }
+                // [crate] Ray::intersects_aabb per child, same arithmetic as the per-triangle test below, so a parent
+                // box (exact union of its children) can never reject what a triangle's own box accepts.  Written with
+                // scalars and selects only (no arrays, no short-circuit branches): keeps the step branch-free.
+                // An unused child slot holds the box (+inf .. +inf), which fails the test for every ray; a NaN tmin keeps
+                // the child (NaN > x is false) and simply does not take part in the ordering.
+#define TRR_BOX(T, R, LX, LY, LZ, HX, HY, HZ, CH)                                                          \
+    float T;                                                                                               \
+    uint32_t R;                                                                                            \
+    {                                                                                                      \
+        float ax = ((LX) - oo.x) * oi.x, bx = ((HX) - oo.x) * oi.x;                                        \
+        float ay = ((LY) - oo.y) * oi.y, by = ((HY) - oo.y) * oi.y;                                        \
+        float az = ((LZ) - oo.z) * oi.z, bz = ((HZ) - oo.z) * oi.z;                                        \
+        float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));                                 \
+        float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));                                 \
+        bool hit = (tmax > rmax(tmin, 0.0f)) & !(tmin > lim_n);                                            \
+        T = hit ? tmin : INFINITY;                                                                         \
+        R = hit ? (CH) : REF_EMPTY;                                                                        \
+    }
+                TRR_BOX(t0, r0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x)
+                TRR_BOX(t1, r1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y)
+                TRR_BOX(t2, r2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
+                TRR_BOX(t3, r3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
+#undef TRR_BOX
+                // sort the four (tmin, ref) pairs ascending: 5-comparator network of selects
+#define TRR_CSWAP(TI, RI, TJ, RJ)                                                  \
+    {                                                                              \
+        bool sw_ = TJ < TI;                                                        \
+        float ta_ = sw_ ? TJ : TI, tb_ = sw_ ? TI : TJ;                            \
+        uint32_t ra_ = sw_ ? RJ : RI, rb_ = sw_ ? RI : RJ;                         \
+        TI = ta_; TJ = tb_; RI = ra_; RJ = rb_;                                    \
+    }
+                TRR_CSWAP(t0, r0, t1, r1) TRR_CSWAP(t2, r2, t3, r3) TRR_CSWAP(t0, r0, t2, r2)
+                TRR_CSWAP(t1, r1, t3, r3) TRR_CSWAP(t1, r1, t2, r2)
+#undef TRR_CSWAP
+                // far children go on the stack, farthest first.  Fast path: three unconditional LDS stores, the stack
+                // pointer advances only past valid entries (a slot above the top may hold garbage).
+                if (sp + 3 <= STACK_LDS) {
+                    const int i3 = sp, i2 = i3 + (r3 != REF_EMPTY ? 1 : 0), i1 = i2 + (r2 != REF_EMPTY ? 1 : 0);
+                    s_stack[i3 * TRACE_THREADS + tid] = make_uint2(r3, __float_as_uint(t3));
+                    s_stack[i2 * TRACE_THREADS + tid] = make_uint2(r2, __float_as_uint(t2));
+                    s_stack[i1 * TRACE_THREADS + tid] = make_uint2(r1, __float_as_uint(t1));
+                    sp = i1 + (r1 != REF_EMPTY ? 1 : 0);
+                } else {
+                    if (r3 != REF_EMPTY) push(r3, t3);
+                    if (r2 != REF_EMPTY) push(r2, t2);
+                    if (r1 != REF_EMPTY) push(r1, t1);
+                }
+                cur = (r0 != REF_EMPTY) ? r0 : pop();
+            }
+        } else if (m_leaf != 0ull) {
+            // ---- leaf: own-box test + exact test of the leaf's next TRR_TRIS_PER_STEP remaining triangles ------------
+            if (cur >= REF_LEAF && cur < REF_IDLE) {
+                const uint32_t slot = (cur & 0x7FFFFFFFu) >> 2;
+                if (COUNT) {
+                    if (lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) c_wtri++;
+                }
+                // one triangle: triangle.rs:88-95 box (empty.grow(a).grow(b).grow(c + 1e-4)) + [crate] slab test, then the
+                // exact test; candidates are ranked by (key, triangle id), so the order of the tests does not matter
+                auto test_one = [&](uint32_t sl, float4 q0, float4 q1, float4 q2, float4 q3) {
+                    if (COUNT) c_boxes++;
+                    bool cand = true;
+                    if (!(fl & F_SKIPBOX)) {
+                        F3 a = f3(q0.x, q0.y, q0.z), b = f3(q0.w, q1.x, q1.y), c = f3(q1.z, q1.w, q2.x);
+                        F3 c2 = f3(c.x + 0.0001f, c.y + 0.0001f, c.z + 0.0001f);
+                        F3 lo = f3(rmin(rmin(a.x, b.x), c2.x), rmin(rmin(a.y, b.y), c2.y), rmin(rmin(a.z, b.z), c2.z));
+                        F3 hi = f3(rmax(rmax(a.x, b.x), c2.x), rmax(rmax(a.y, b.y), c2.y), rmax(rmax(a.z, b.z), c2.z));
+                        float ax = (lo.x - oo.x) * oi.x, bx = (hi.x - oo.x) * oi.x;
+                        float ay = (lo.y - oo.y) * oi.y, by = (hi.y - oo.y) * oi.y;
+                        float az = (lo.z - oo.z) * oi.z, bz = (hi.z - oo.z) * oi.z;
+                        float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));
+                        float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));
+                        // the second condition: cannot beat the current best (slack keeps this conservative)
+                        cand = (tmax > rmax(tmin, 0.0f)) && !(tmin > lim_n);
+                    }
+                    if (cand) {
+                        if (COUNT) c_tris++;
+                        TriHit h;
+                        if (tri_test(q0, q1, q2, q3.z, oo, od, delta, h)) {
+                            uint32_t tri_id = __float_as_uint(q3.x);
+                            if (candidate_better((fl & F_OHAVE) != 0u, h.key, tri_id, o_key, o_tri)) {
+                                fl |= F_OHAVE; o_key = h.key; o_slot = sl; o_tri = tri_id;
+                                float dist = sqrtf(h.key);
+                                if (dist == dist) lim_n = rmin(lim_n, dist * (1.0f + PRUNE_REL) + slack_abs);
+                            }
+                        }
+                    }
+                };
+                const float4* tp = reinterpret_cast<const float4*>(g_tris + slot);
+#if TRR_TRIS_PER_STEP >= 2
+                // both records are requested before the first is used: the second one's latency hides behind the first test
+                uint32_t sl = slot;
+                const bool two = (cur & 3u) != 0u;
+                const float4* tq = two ? tp + 4 : tp;
+                float4 a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3];
+                float4 b0 = tq[0], b1 = tq[1], b2 = tq[2], b3 = tq[3];
+                test_one(sl, a0, a1, a2, a3);
+                if (two) test_one(sl + 1u, b0, b1, b2, b3);
+                // ref = LEAF | first << 2 | count-1: two triangles consumed -> first+2, count-2
+                cur = ((cur & 3u) >= 2u) ? cur + 6u : pop();
+#else
+                test_one(slot, tp[0], tp[1], tp[2], tp[3]);
+                // next triangle of the leaf (ref = LEAF | first << 2 | count-1  ->  first+1, count-2), else pop
+                cur = (cur & 3u) ? cur + 3u : pop();
+#endif
+            }
+        }
