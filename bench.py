@@ -8,17 +8,23 @@ reference's hard-coded value, render.rs:105), 4 point lights of res/test/config.
 every rank renders its blocks of the reference's 20x20 block grid (block id % N == rank) into a device strip, one
 gather brings the strips to rank 0, rank 0 de-interleaves them into the row-major RGB8 frame.  The frame is the
 same for every N (strong scaling); scene, BVH and all work buffers are resident in HBM before the timed region.
-Consecutive frames alternate between two buffer sets / render streams (--frames-in-flight 2), so the head of frame k+1
-overlaps the tail of frame k; ms_per_step is elapsed / K (throughput), roofline.frame_latency_ms is one frame's own
-first-kernel-start to last-kernel-end time.
+
+The reference renders ONE frame per click (raytracer/render.rs:39-71), so the timed frames run one after the other
+(--frames-in-flight 1): ms_per_step is the latency of a frame and `value` = rays of a frame / that latency.  A second,
+untimed-for-the-metric loop with two frames in flight gives the throughput of a frame SEQUENCE (`pipelined` in the line).
 
 Rays are counted by the rule of SURVEY.md section 8(d) (primaries + one shadow query per shaded hit and light + one
 reflection per reflective hit + transparency-march queries); the CPU baseline is credited the same rays for the
 same blocks, so GPU/CPU ratio == time ratio.
+
+Roofline: the path is fp32 VALU work on cache-resident data -- no MFMA, 3 % of the HBM peak -- so
+the roof is the fp32 vector peak.  `achieved` = ALGORITHMIC flops of a frame / frame time, the flops from the counter
+build's measured unit counts times the per-unit constants below; nothing in the line can imply more than a peak.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,17 +33,24 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-# per-unit ALGORITHMIC bytes of the trace kernel (DESIGN.md "Roofline"): one visited BVH4 node = one 128-B line,
-# one tested triangle = one 64-B record, plus each ray's queue record in (32 B; camera rays are generated in
-# registers) and its result out (32-B hit record for camera/reflection rays, 4-B occluder code for shadow rays).
-NODE_B, TRI_B, RAY_IN_B, HIT_OUT_B, OCC_OUT_B = 128, 64, 32, 32, 4
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
+# ---- per-unit ALGORITHMIC flops (fp32 add / mul / div / sqrt / min / max / compare / select, one each), DESIGN.md section 4 ----
+NODE_FLOP = 125      # one lane visiting one 4-wide node: 4 slab tests (6 sub, 6 mul, 10 min/max, 3 compare) + 5-comparator sort of selects
+BOX_FLOP = 40        # a leaf triangle's own box (triangle.rs:88-95): 3 add, 12 min/max, then the slab test
+TRI_FLOP = 95        # the exact test of triangle.rs:53-85 incl. the interpolated point and its distance (object.rs:201, 206)
+RAY_FLOP = 90        # a ray's start per object: object-space origin / direction, norm, 6 divisions (object.rs:186-195)
+SETUP_FLOP = 200     # a shaded hit's set-up: exact test again, normal / uv interpolation, two transforms (object.rs:198-219)
+LIGHT_FLOP = 60      # shade_impl per (shaded hit, light): normalise, transmission, diffuse + specular terms (mod.rs:148-208)
+HIT_FLOP = 40        # shade_impl per shaded hit outside the light loop (mod.rs:129-146)
+VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak, /opt/skills/guides/MI355X_MICROARCH.md ("Peak FP32")
+HBM_PEAK_GBS = 8000.0      # same guide
+N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2   # 256 CUs x 4 SIMDs; a wave64 VALU instruction issues over 2 cycles (same guide)
 
 
-def trace_bytes(st) -> float:
-    secondary = st.rays_shadow + st.rays_reflection
-    return (NODE_B * st.node_visits + TRI_B * st.tri_tests + RAY_IN_B * secondary +
-            HIT_OUT_B * (st.rays_primary + st.rays_reflection) + OCC_OUT_B * st.rays_shadow)
+def frame_flops(st, n_lights, n_objs=1) -> float:
+    leaf_boxes = max(0, st.box_tests - 4 * st.node_visits)
+    shaded = st.rays_shadow / max(1, n_lights)
+    return (NODE_FLOP * st.node_visits + BOX_FLOP * leaf_boxes + TRI_FLOP * st.tri_tests + RAY_FLOP * st.rays() * n_objs +
+            shaded * (SETUP_FLOP + HIT_FLOP + LIGHT_FLOP * n_lights))
 
 
 def main():
@@ -50,14 +63,16 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--max-depth", type=int, default=5)
-    ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="buffer sets / render streams alternated by consecutive frames (1 = each frame waits for the previous one)")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="buffer sets / render streams alternated by consecutive TIMED frames (1 = every frame waits for the one before: latency)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the second loop (two frames in flight, sequence throughput)")
     ap.add_argument("--no-launch-events", action="store_true",
                     help="experiment: time the frames without per-launch HIP events (the roofline object is then null)")
     ap.add_argument("--build", choices=("host", "device"), default="host",
                     help="where the BVH is built (outside the timed region): host SAH (default, best tree) or GPU LBVH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "16")))
+    ap.add_argument("--cpu-runs", type=int, default=3, help="CPU baseline runs; the median is reported")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,10 +103,10 @@ def main():
 
     aa = args.spp > 1
     scene = standin.standin_car(args.width, args.height, n_tris=args.tris, seed=1, anti_aliasing=aa, samples=max(1, args.spp))
+    n_lights = len(scene.lights)
     t0 = time.perf_counter()
     rt = Raytracer(scene, max_depth=args.max_depth, device=local_rank, build=args.build)
     upload_s = time.perf_counter() - t0
-    sr = ShardedRenderer(rt, rank, world, use_dist=distributed, frames_in_flight=args.frames_in_flight)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -99,30 +114,34 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_loop(sr, steps, stats):
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            sr.render(stats=stats[k] if stats else None, defer_stats=True)   # events recorded now, read after the timed region
+        sync_all()
+        el = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # ---- timed region: exactly K frames; per-launch HIP events (library side, on the launch streams) give the trace
+    # kernels' durations over the same frames ------------------------------------------------------------------
+    sr = ShardedRenderer(rt, rank, world, use_dist=distributed, frames_in_flight=args.frames_in_flight)
     for _ in range(args.warmup):
         sr.render()
-    sync_all()
-
-    # ---- timed region: exactly K frames; per-launch HIP events (library side, on the launch stream) give the
-    # trace kernel's durations over the same frames ----------------------------------------------------------
-    stats = [N.Stats() for _ in range(args.steps)]
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        sr.render(stats=None if args.no_launch_events else stats[k], defer_stats=True)   # events recorded now, read after the timed region
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    stats = [] if args.no_launch_events else [N.Stats() for _ in range(args.steps)]
+    elapsed = timed_loop(sr, args.steps, stats)
     rt.ctx.collect_stats()
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # rays of the whole frame = sum over ranks of their shard's rays (deterministic per frame)
     if args.no_launch_events:   # ray counts from one untimed frame
+        stats = [N.Stats()]
         sr.render(stats=stats[-1])
         torch.cuda.synchronize()
-    my_rays = stats[-1].rays() if stats else 0
+    my_rays = stats[-1].rays()
     if distributed:
         t = torch.tensor([my_rays], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -130,47 +149,65 @@ def main():
     else:
         frame_rays = int(my_rays)
 
-    # ---- untimed: counter build of rank 0's shard -> nodes visited / triangles tested (algorithmic bytes) -------
+    # ---- untimed for the metric: the same K frames with two in flight (throughput of a frame sequence) -------------
+    pipelined = None
+    if not args.no_pipelined and args.steps > 0:
+        sr2 = ShardedRenderer(rt, rank, world, use_dist=distributed, frames_in_flight=2)
+        for _ in range(2):
+            sr2.render()
+        el2 = timed_loop(sr2, args.steps, None)
+        pipelined = {"frames_in_flight": 2, "ms_per_frame": round(el2 / args.steps * 1e3, 3),
+                     "mrays_per_s": round(frame_rays * args.steps / el2 / 1e6, 2)}
+        del sr2
+
+    # ---- untimed: counter build of rank 0's shard -> nodes visited / triangles tested (algorithmic flops) ----------
     roofline = None
     cst = N.Stats()
     sr.render(stats=cst, counters=True)
     torch.cuda.synchronize()
     if rank == 0 and args.steps > 0 and not args.no_launch_events:
+        frame_s = elapsed / args.steps
         launches = sum(s.trace_launches for s in stats)
         ms_trace = sum(s.ms_trace for s in stats)
-        avg_ms = ms_trace / max(1, launches)
-        bytes_per_launch = trace_bytes(cst) / max(1, cst.trace_launches)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic per launch: not measurable from inside the process; taken from the committed PMC passes of this same
-        # command (profiles/hbm_traffic.json, made by scripts/profile_pmc.sh + scripts/pmc_traffic.py), else null
-        traffic = None
+        flops = frame_flops(cst, n_lights) * (frame_rays / max(1, cst.rays()))   # rank 0's shard scaled to the frame
+        achieved = flops / frame_s / 1e12
+        # committed PMC passes of this same command (profiles/pmc_frame.json, made by scripts/profile_pmc.sh +
+        # scripts/pmc_frame.py at the commit named in the file): VALU instructions and HBM bytes of ONE frame
+        pmc = None
         try:
-            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-                traffic = int(json.load(f)["kernels"]["k_trace"]["hbm_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
+            with open(os.path.join(ROOT, "profiles", "pmc_frame.json")) as f:
+                pmc = json.load(f)
+        except (OSError, ValueError):
             pass
-        frame_s = elapsed / args.steps
+        one_gpu = world == 1 and pmc is not None
         roofline = {
-            "bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            # launches of up to 3 batches overlap on separate streams, so launch durations add up to more than the
-            # frame; the second figure divides the same algorithmic bytes by the whole frame time instead
-            "achieved_over_frame_time": round(trace_bytes(cst) / frame_s / 1e9, 2),
-            "note": "algorithmic bytes; the working set is Infinity-Cache/L2 resident, see DESIGN.md section 4",
-            "avg_launch_ms": round(avg_ms, 4), "launches_per_frame": launches // max(1, args.steps),
-            "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "bound": "valu", "kernel": "k_trace_level (camera-ray + secondary-ray launches)",
+            "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TFLOPS, 5),
+            "traffic": int(pmc["hbm_bytes_per_frame"]) if one_gpu else None,
+            "note": "fp32 vector work on an L2 / Infinity-Cache resident scene: no MFMA, HBM far from its peak (hbm_frac); achieved = "
+                    "algorithmic flops of the frame / frame time, so no figure here can exceed a peak; see DESIGN.md section 4",
+            "algorithmic_gflop_per_frame": round(flops / 1e9, 1),
+            "flop_constants": {"node": NODE_FLOP, "leaf_box": BOX_FLOP, "tri": TRI_FLOP, "ray_start": RAY_FLOP, "setup": SETUP_FLOP,
+                               "hit": HIT_FLOP, "light": LIGHT_FLOP},
+            # the contract's per-launch form: launches of up to 3 batches overlap on separate streams, so their durations add up
+            # to more than the frame and this figure is BELOW `achieved`
+            "per_launch": {"launches_per_frame": launches // max(1, args.steps), "avg_launch_ms": round(ms_trace / max(1, launches), 4),
+                           "achieved": round(flops * args.steps / max(1e-9, ms_trace * 1e-3) / 1e12, 3)},
+            "valu_issue_frac": round(pmc["valu_insts_per_frame"] * VALU_CYCLES / (N_SIMD * CLOCK_HZ * frame_s), 4) if one_gpu else None,
+            "hbm_frac": round(pmc["hbm_bytes_per_frame"] / frame_s / 1e9 / HBM_PEAK_GBS, 4) if one_gpu else None,
+            "pmc_source": {"file": "profiles/pmc_frame.json", "commit": pmc.get("commit"), "frames": pmc.get("frames")} if one_gpu else None,
+            "lane_util_node_steps": round(cst.node_visits / max(1, 64 * cst.wave_node_steps), 4),
             "nodes_per_ray": round(cst.node_visits / max(1, cst.rays()), 2),
             "tris_per_ray": round(cst.tri_tests / max(1, cst.rays()), 2),
-            "frame_latency_ms": round(sum(s.ms_total for s in stats) / args.steps, 3),
-            "trace_ms_per_frame": round(ms_trace / args.steps, 3),
-            "shade_ms_per_frame": round(sum(s.ms_shade for s in stats) / args.steps, 3),
+            "trace_ms_per_frame_summed": round(ms_trace / args.steps, 3),
+            "shade_ms_per_frame_summed": round(sum(s.ms_shade for s in stats) / args.steps, 3),
         }
 
     # ---- untimed, rank 0 at N=1 only: the CPU oracle in reference-literal mode on a bounded block sample ---------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
-        first, step = 0, 2   # every second block: 200 of the 400 blocks, spread evenly over rows and columns (~8-15 s of CPU)
+        first, step = 0, 2   # every second block: 200 of the 400 blocks, spread evenly over rows and columns (~7 s of CPU per run)
         gst = N.Stats()
         sb = rt.strip_bytes(step)
         tmp = torch.zeros(sb, dtype=torch.uint8, device="cuda")
@@ -178,9 +215,13 @@ def main():
         rt.render_shard_device(first, step, tmp.data_ptr(), sb, stats=gst)
         torch.cuda.synchronize()
         osc = oracle.OracleScene(scene)
-        res = osc.render(max_depth=args.max_depth, accel=oracle.ACCEL_BVH, shade=oracle.SHADE_LITERAL,
-                         threads=args.cpu_threads, block_first=first, block_step=step, want_ids=False)
+        secs, res = [], None
+        for _ in range(max(1, args.cpu_runs)):
+            res = osc.render(max_depth=args.max_depth, accel=oracle.ACCEL_BVH, shade=oracle.SHADE_LITERAL,
+                             threads=args.cpu_threads, block_first=first, block_step=step, want_ids=False)
+            secs.append(res["counters"].seconds)
         cn = res["counters"]
+        med = statistics.median(secs)
         # parity spot check of the very blocks that were timed
         from raytracing_amd.multigpu import strip_from_frame
         gpu_strip = tmp.cpu().numpy()
@@ -189,12 +230,13 @@ def main():
         npx = nb * (args.width // 20) * (args.height // 20)
         d = np.abs(gpu_strip[:npx * 3].astype(np.int16) - ref_strip[:npx * 3].astype(np.int16)).reshape(-1, 3).max(axis=1)
         cpu = {
-            "value": round(gst.rays() / cn.seconds / 1e6, 4), "unit": "Mrays/s", "cores": args.cpu_threads, "kind": "port",
+            "value": round(gst.rays() / med / 1e6, 4), "unit": "Mrays/s", "cores": args.cpu_threads, "kind": "port",
             "sample": f"blocks {first}::{step} ({nb} of 400 blocks of the same {args.width}x{args.height} {args.spp}spp frame), "
                       f"C++ restatement in reference-literal mode (per-call matrix inverse, one-triangle-leaf BVH, all "
-                      f"candidates tested, reflection re-traced per light), {args.cpu_threads} threads over blocks",
-            "seconds": round(cn.seconds, 3), "rays_credited": int(gst.rays()), "literal_raycasts": int(cn.raycasts),
-            "host_cpus": os.cpu_count(),
+                      f"candidates tested, reflection re-traced per light), {args.cpu_threads} threads over blocks, "
+                      f"median of {len(secs)} runs",
+            "seconds": round(med, 3), "seconds_runs": [round(x, 3) for x in secs], "rays_credited": int(gst.rays()),
+            "literal_raycasts": int(cn.raycasts), "host_cpus": os.cpu_count(),
             "parity_within_1lsb": round(float((d <= 1).mean()), 6), "parity_exact": round(float((d == 0).mean()), 6),
         }
         osc.close()
@@ -208,10 +250,10 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"car_objs stand-in (procedural, {scene.triangle_count()} triangles, one object) "
                                    f"{args.width}x{args.height}, {args.spp} spp, max_depth {args.max_depth} "
-                                   f"(reflection depth {args.max_depth - 1}), 4 lights, tiles sharded over {world} GPU(s)",
+                                   f"(reflection depth {args.max_depth - 1}), {n_lights} lights, tiles sharded over {world} GPU(s)",
                        "rays_per_frame": frame_rays, "scene_upload_s": round(upload_s, 2), "bvh_build": args.build,
                        "frames_in_flight": args.frames_in_flight},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "pipelined": pipelined, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     rt.close()

@@ -566,13 +566,18 @@ struct Raytracer {   // raytracer/mod.rs:26-43
     }
 
     // raytracer/mod.rs:96-114  raycast_transparent(...).last()
+    // The reference's loop has no bound and spins for ever on a ray that cannot advance (zero or NaN direction inside a
+    // transparent surface).  Restatement and GPU kernels share a cap of 65535 marching steps per ray (3 276 scene units of
+    // glass at |d| = 1), reachable only where the reference itself would not return.
     bool raycast_transparent_last(Ray ray, Hit* last, Counters& cn) const {
         bool have = false;
         Hit h;
+        uint32_t marches = 0;
         while (raycast(ray, &h, cn)) {
             *last = h; have = true;
-            if (h.material && h.material->transparency()) {
+            if (h.material && h.material->transparency() && marches < 0xFFFFu) {
                 ray.o = add(ray.o, scale(ray.d, 0.05f));   // :106
+                ++marches;
                 continue;
             }
             break;
