@@ -9,9 +9,13 @@
  *
  * Rules of the boundary: plain pointers and sizes only; every pointer passed IN is borrowed for the
  * duration of the call; opaque handles are owned by the library; no entry point aborts -- all return
- * TRR_OK (0) or a negative trr_status and leave a message for trr_last_error().  One process drives one
- * GPU; multi-GPU rendering = one process (rank) per GPU, each rendering its shard of the reference's own
- * 20x20 block grid (render.rs:103-110) and one gather of the RGB8 strips (see trr_render_shard_device).
+ * TRR_OK (0) or a negative trr_status and leave a message for trr_last_error().  Multi-GPU rendering shards the
+ * reference's own 20x20 block grid (render.rs:103-110) over the GPUs (block id % N), scene replicated, one gather of
+ * the RGB8 strips.  Two forms: inside ONE process -- the reference's host has one process and one render thread
+ * (render.rs:39-71) -- a context made by trr_create_multi drives all its devices behind trr_render /
+ * trr_render_blocks; or one process (rank) per GPU, each calling trr_render_shard_device, the strips gathered by the
+ * caller (torch.distributed / RCCL) and assembled by trr_assemble_device.
+ * Destroy scenes before their context.  Every entry point leaves the calling thread's current HIP device as it was.
  */
 #ifndef TRAYRACER_HIP_H
 #define TRAYRACER_HIP_H
@@ -133,6 +137,14 @@ typedef void (*trr_progress_cb)(void* user, uint32_t blocks_done, uint32_t block
 /* ---- context -------------------------------------------------------------------------------- */
 /* Replaces nothing in the reference (it has no device).  Selects GPU `device_id` for this process. */
 int trr_create(int device_id, trr_ctx** out);
+/* The same for N GPUs of this process (1 <= n_devices <= 64, distinct ids; the first is the root that assembles the
+ * frame).  Scenes created on such a context are uploaded to every device, the setters reach every copy, and trr_render /
+ * trr_render_blocks render block b on device b % N and bring the strips to the root with ONE ncclGather (RCCL over
+ * xGMI; librccl is loaded on first use, a single-device context never needs it).  The Rust shim of INTEGRATION.md uses
+ * all GPUs of a node by changing its trr_create call into this one.  trr_render_shard_device* and the hit-id buffers of
+ * trr_render need a single-device context.  No counterpart in the reference (it has no device). */
+int trr_create_multi(const int* device_ids, int n_devices, trr_ctx** out);
+int trr_device_count(const trr_ctx* ctx);   /* devices the context drives (1 for trr_create) */
 void trr_destroy(trr_ctx* ctx);
 /* Last error text of `ctx` (or of the calling thread when ctx is NULL).  Never NULL. */
 const char* trr_last_error(const trr_ctx* ctx);
@@ -221,6 +233,9 @@ int trr_render_shard_device(trr_ctx* ctx, trr_scene* scene, float delta, uint32_
                             const volatile int32_t* cancel_flag, trr_progress_cb progress, void* user,
                             trr_stats* stats_out);
 size_t trr_strip_bytes(uint32_t width, uint32_t height, uint32_t n_shards);
+/* The partition itself (host arithmetic, no GPU): writes the row-major block ids (render.rs:109-110, 129-130) that `shard`
+ * of `n_shards` renders, in strip order, into block_ids (up to `capacity`; NULL to only count) and returns their number. */
+uint32_t trr_shard_blocks(uint32_t width, uint32_t height, uint32_t shard, uint32_t n_shards, uint32_t* block_ids, uint32_t capacity);
 
 /* The entry point that allocates nothing.  It has NO counterpart in the reference; it exists for callers that cannot call
  * hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same arguments, strip

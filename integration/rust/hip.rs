@@ -35,6 +35,7 @@ type BlockCb = extern "C" fn(*mut c_void, u32, u32, u32, u32, *const u8);
 
 extern "C" {
     fn trr_create(device: c_int, out: *mut *mut c_void) -> c_int;
+    fn trr_create_multi(device_ids: *const c_int, n_devices: c_int, out: *mut *mut c_void) -> c_int;
     fn trr_destroy(ctx: *mut c_void);
     fn trr_last_error(ctx: *const c_void) -> *const c_char;
     fn trr_scene_create_ex(ctx: *mut c_void, objs: *const TrrObject, n: u32, tex: *const TrrImage, n_tex: u32, build: u32,
@@ -52,7 +53,8 @@ pub const BUILD_HOST: u32 = 0;    // TRR_BUILD_HOST: binned-SAH tree on the CPU 
 pub const BUILD_DEVICE: u32 = 1;  // TRR_BUILD_DEVICE: LBVH on the GPU (while the scene is being edited)
 const ERR_CANCELLED: c_int = -4;
 
-/// One GPU of this process (`trr_ctx`).  Not `Sync`: exactly one render is in flight (ui/statusbar.rs:142-157).
+/// One GPU of this process, or all GPUs of the node behind one context (`trr_ctx`).  Not `Sync`: exactly one render is in
+/// flight (ui/statusbar.rs:142-157).
 pub struct Backend { ctx: *mut c_void }
 unsafe impl Send for Backend {}
 
@@ -61,6 +63,15 @@ impl Backend {
         let mut ctx = std::ptr::null_mut();
         let rc = unsafe { trr_create(device, &mut ctx) };
         if rc != 0 { bail!("no HIP device: {}", last_error(std::ptr::null())); }
+        Ok(Self { ctx })
+    }
+
+    /// Several GPUs behind ONE context: the library replicates every uploaded scene, deals the 20x20 block grid round-robin
+    /// (block id % N), and gathers the strips with one ncclGather; `render_blocks` below needs no change to use them.
+    pub fn new_multi(devices: &[i32]) -> anyhow::Result<Self> {
+        let mut ctx = std::ptr::null_mut();
+        let rc = unsafe { trr_create_multi(devices.as_ptr(), devices.len() as c_int, &mut ctx) };
+        if rc != 0 { bail!("trr_create_multi: {}", last_error(std::ptr::null())); }
         Ok(Self { ctx })
     }
 

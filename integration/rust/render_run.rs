@@ -12,7 +12,8 @@ fn render_on_gpu(
     progress: &AtomicU16,
     mut paint: impl FnMut(Vec<Color32>, u32, u32),
 ) -> anyhow::Result<bool> {
-    let gpu = hip::Backend::new(0)?;                    // one per process in a real integration (a `OnceLock`)
+    let gpu = hip::Backend::new(0)?;                    // one per process in a real integration (a `OnceLock`);
+                                                        // hip::Backend::new_multi(&[0, 1, 2, 3, 4, 5, 6, 7]) uses a whole node
     let on_gpu = gpu.upload(scene, hip::BUILD_HOST)?;    // stands in for Raytracer::new(scene, 1e-5, 5), render.rs:105
     let mut on_block = |rgb: &[u8], x_block: u32, y_block: u32, _w: u32, _h: u32| {
         paint(rgb.chunks_exact(3).map(|p| Color32::from_rgb(p[0], p[1], p[2])).collect(), x_block, y_block);

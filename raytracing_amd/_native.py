@@ -87,7 +87,7 @@ BLOCK_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c
 
 # every symbol include/trayracer_hip.h declares
 EXPORTS = [
-    "trr_create", "trr_destroy", "trr_last_error", "trr_scene_create", "trr_scene_create_ex", "trr_scene_get_info",
+    "trr_create", "trr_create_multi", "trr_device_count", "trr_shard_blocks", "trr_destroy", "trr_last_error", "trr_scene_create", "trr_scene_create_ex", "trr_scene_get_info",
     "trr_scene_validate", "trr_scene_destroy", "trr_scene_set_instances",
     "trr_scene_set_lights", "trr_scene_set_settings", "trr_scene_set_camera", "trr_render", "trr_render_blocks", "trr_render_shard_device",
     "trr_strip_bytes", "trr_render_shard_device_noalloc", "trr_noalloc_scratch_bytes", "trr_assemble_device", "trr_synchronize", "trr_collect_stats", "trr_object_matrices", "trr_camera_ray", "trr_version",
@@ -127,6 +127,13 @@ def lib() -> C.CDLL:
     L.trr_last_error.argtypes = [vp]
     L.trr_create.restype = i32
     L.trr_create.argtypes = [i32, C.POINTER(vp)]
+    if hasattr(L, "trr_create_multi"):
+        L.trr_create_multi.restype = i32
+        L.trr_create_multi.argtypes = [vp, i32, C.POINTER(vp)]
+        L.trr_device_count.restype = i32
+        L.trr_device_count.argtypes = [vp]
+        L.trr_shard_blocks.restype = u32
+        L.trr_shard_blocks.argtypes = [u32, u32, u32, u32, vp, u32]
     L.trr_destroy.restype = None
     L.trr_destroy.argtypes = [vp]
     L.trr_scene_create.restype = i32

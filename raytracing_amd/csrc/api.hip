@@ -6,6 +6,7 @@
 //   trr_render*       <- RenderingThread::run block loop                raytracer/render.rs:95-193
 //   host math helpers <- Object::transform, Camera::ray (nalgebra)      scene/object.rs:177-182, scene/camera.rs:30-42
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -14,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -78,6 +80,11 @@ struct trr_ctx {
     int bpc[2] = {0, 0};                 // resident 256-thread blocks per CU of k_trace<COUNT> (occupancy query, once)
     int bpc_level[2][2] = {{0, 0}, {0, 0}};   // ... of k_trace_level<RAYGEN, COUNT>
     unsigned char* scratch = nullptr;    // this device's copy of the static `scratch` array (hipGetSymbolAddress in trr_create)
+    // a multi-device context (trr_create_multi) owns one plain context per device and drives them; it has no streams or
+    // work buffers of its own.  subs[0] is the root: it receives the gathered strips and assembles the frame.
+    std::vector<trr_ctx*> subs;
+    std::vector<void*> comms;            // ncclComm_t per device (RCCL, loaded on demand); empty while no gather is needed
+    DevBuf gathered;                     // on subs[0]'s device: the strips of all devices
     uint32_t rotate = 0;                 // round-robin start lane of single-batch frames
     uint64_t budget_total = 0;           // bytes the work sets of all lanes may take together (set at the first render)
     size_t events_used = 0;              // events handed to frames whose statistics are still pending
@@ -102,6 +109,8 @@ struct trr_ctx {
 
 struct trr_scene {
     trr_ctx* ctx = nullptr;
+    int device = 0;                      // ctx->device, kept so that trr_scene_destroy does not touch the context
+    std::vector<trr_scene*> replicas;    // scene of a multi-device context: one uploaded copy per device, nothing else
     DevBuf nodes, tris, interp, objs, mats, texs, texels, lights, sky;
     std::vector<ObjRec> h_objs;
     uint32_t n_objs = 0, n_lights = 0, n_mats = 0, n_tex = 0;
@@ -161,6 +170,20 @@ static int upload(trr_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
 }
 
 static void finish_stats(trr_ctx* ctx, const trr_ctx::PendingStats& f);
+
+// Restores the calling thread's current device when an entry point returns (every entry point selects its context's).
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+static bool is_multi(const trr_ctx* ctx) { return ctx && !ctx->subs.empty(); }
+static void multi_destroy(trr_ctx* ctx);
+static int multi_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_objects, const trr_image_rgb8* textures,
+                              uint32_t n_textures, uint32_t build, trr_scene** out);
+static int multi_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t flags, uint8_t* rgb_out,
+                        const volatile int32_t* cancel_flag, trr_progress_cb progress, void* user, trr_stats* stats_out);
 
 // ---- extern "C" ---------------------------------------------------------------------------------------------
 extern "C" {
@@ -224,6 +247,8 @@ int trr_create(int device_id, trr_ctx** out) {
 
 void trr_destroy(trr_ctx* ctx) {
     if (!ctx) return;
+    DeviceGuard guard;
+    if (is_multi(ctx)) { multi_destroy(ctx); return; }
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto& w : ctx->ws) {
@@ -243,6 +268,12 @@ void trr_destroy(trr_ctx* ctx) {
 
 int trr_collect_stats(trr_ctx* ctx) {
     if (!ctx) return fail(nullptr, TRR_ERR_INVALID, "trr_collect_stats: ctx is NULL");
+    DeviceGuard guard;
+    if (is_multi(ctx)) {
+        int rc = TRR_OK;
+        for (trr_ctx* c : ctx->subs) { int r = trr_collect_stats(c); if (r != TRR_OK) { rc = fail(ctx, r, c->err); } }
+        return rc;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = TRR_OK;
     for (auto& f : ctx->pending) {
@@ -261,6 +292,11 @@ int trr_collect_stats(trr_ctx* ctx) {
 
 int trr_synchronize(trr_ctx* ctx, void* stream) {
     if (!ctx) return fail(nullptr, TRR_ERR_INVALID, "trr_synchronize: ctx is NULL");
+    DeviceGuard guard;
+    if (is_multi(ctx)) {
+        for (trr_ctx* c : ctx->subs) { int r = trr_synchronize(c, nullptr); if (r != TRR_OK) return fail(ctx, r, c->err); }
+        return TRR_OK;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
     return TRR_OK;
@@ -450,6 +486,8 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
     if (n_objects && !objects) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: objects is NULL");
     if (n_textures && !textures) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: textures is NULL");
     if (build != TRR_BUILD_HOST && build != TRR_BUILD_DEVICE) return fail(ctx, TRR_ERR_INVALID, "trr_scene_create_ex: unknown build mode");
+    DeviceGuard guard;
+    if (is_multi(ctx)) return multi_scene_create(ctx, objects, n_objects, textures, n_textures, build, out);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const auto t_start = std::chrono::steady_clock::now();
 
@@ -587,6 +625,7 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
 
     trr_scene* sc = new trr_scene();
     sc->ctx = ctx;
+    sc->device = ctx->device;
     sc->n_objs = n_objects;
     sc->h_objs = objs;
     sc->n_nodes = nodes.size();
@@ -641,6 +680,7 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
 
 int trr_scene_get_info(const trr_scene* sc, trr_scene_info* out) {
     if (!sc || !out) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_get_info: NULL argument");
+    if (!sc->replicas.empty()) return trr_scene_get_info(sc->replicas[0], out);
     out->n_triangles = sc->n_tris_total;
     out->n_triangles_live = sc->n_tris_live;
     out->n_nodes = sc->n_nodes;
@@ -653,6 +693,11 @@ int trr_scene_get_info(const trr_scene* sc, trr_scene_info* out) {
 
 int trr_scene_validate(trr_scene* sc) {
     if (!sc) return fail(nullptr, TRR_ERR_INVALID, "trr_scene_validate: NULL argument");
+    DeviceGuard guard;
+    if (!sc->replicas.empty()) {
+        for (trr_scene* r : sc->replicas) { int rc = trr_scene_validate(r); if (rc != TRR_OK) return fail(sc->ctx, rc, r->ctx->err); }
+        return TRR_OK;
+    }
     trr_ctx* ctx = sc->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::vector<Node4> nodes(sc->n_nodes);
@@ -724,8 +769,13 @@ int trr_scene_validate(trr_scene* sc) {
 
 void trr_scene_destroy(trr_scene* sc) {
     if (!sc) return;
-    if (sc->ctx) (void)hipSetDevice(sc->ctx->device);
-    if (sc->ctx) (void)hipDeviceSynchronize();
+    DeviceGuard guard;
+    for (trr_scene* r : sc->replicas) trr_scene_destroy(r);
+    sc->replicas.clear();
+    // the device id is the scene's own copy: a scene may be destroyed after its context (the buffers are plain hipMalloc
+    // memory of the device; destroying scenes first is still the documented order)
+    (void)hipSetDevice(sc->device);
+    (void)hipDeviceSynchronize();
     for (DevBuf* b : {&sc->nodes, &sc->tris, &sc->interp, &sc->objs, &sc->mats, &sc->texs, &sc->texels, &sc->lights, &sc->sky})
         release(*b);
     delete sc;
@@ -733,6 +783,11 @@ void trr_scene_destroy(trr_scene* sc) {
 
 int trr_scene_set_instances(trr_scene* sc, const float* transforms, const float* inverses, uint32_t n_objects) {
     if (!sc || !transforms || !inverses) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_set_instances: NULL argument");
+    DeviceGuard guard;
+    if (!sc->replicas.empty()) {
+        for (trr_scene* r : sc->replicas) { int rc = trr_scene_set_instances(r, transforms, inverses, n_objects); if (rc != TRR_OK) return fail(sc->ctx, rc, r->ctx->err); }
+        return TRR_OK;
+    }
     if (n_objects != sc->n_objs) return fail(sc->ctx, TRR_ERR_INVALID, "trr_scene_set_instances: object count mismatch");
     HIPCHK(sc->ctx, hipSetDevice(sc->ctx->device));
     HIPCHK(sc->ctx, hipDeviceSynchronize());
@@ -743,6 +798,12 @@ int trr_scene_set_instances(trr_scene* sc, const float* transforms, const float*
 int trr_scene_set_lights(trr_scene* sc, const trr_light* lights, uint32_t n_lights) {
     if (!sc || (n_lights && !lights)) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_set_lights: NULL argument");
     if (n_lights > 0xFFFFu) return fail(sc->ctx, TRR_ERR_INVALID, "trr_scene_set_lights: more than 65535 lights");
+    DeviceGuard guard;
+    if (!sc->replicas.empty()) {
+        for (trr_scene* r : sc->replicas) { int rc = trr_scene_set_lights(r, lights, n_lights); if (rc != TRR_OK) return fail(sc->ctx, rc, r->ctx->err); }
+        sc->n_lights = n_lights;
+        return TRR_OK;
+    }
     HIPCHK(sc->ctx, hipSetDevice(sc->ctx->device));
     HIPCHK(sc->ctx, hipDeviceSynchronize());
     std::vector<LightRec> l(n_lights);
@@ -757,6 +818,12 @@ int trr_scene_set_lights(trr_scene* sc, const trr_light* lights, uint32_t n_ligh
 
 int trr_scene_set_settings(trr_scene* sc, const trr_settings* s) {
     if (!sc || !s) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_set_settings: NULL argument");
+    DeviceGuard guard;
+    if (!sc->replicas.empty()) {
+        for (trr_scene* r : sc->replicas) { int rc = trr_scene_set_settings(r, s); if (rc != TRR_OK) return fail(sc->ctx, rc, r->ctx->err); }
+        sc->settings = *s; sc->settings.skybox_image.rgb = nullptr; sc->have_settings = true;
+        return TRR_OK;
+    }
     HIPCHK(sc->ctx, hipSetDevice(sc->ctx->device));
     HIPCHK(sc->ctx, hipDeviceSynchronize());
     sc->settings = *s;
@@ -776,6 +843,7 @@ int trr_scene_set_settings(trr_scene* sc, const trr_settings* s) {
 
 int trr_scene_set_camera(trr_scene* sc, const trr_camera* c) {
     if (!sc || !c) return fail(sc ? sc->ctx : nullptr, TRR_ERR_INVALID, "trr_scene_set_camera: NULL argument");
+    for (trr_scene* r : sc->replicas) (void)trr_scene_set_camera(r, c);
     sc->camera = *c;
     camera_basis(c, sc->cam_x, sc->cam_y, sc->cam_z, &sc->cam_focal);
     sc->have_camera = true;
@@ -1243,18 +1311,32 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
 
     // fork: with one lane everything stays on the caller's stream; with several, every lane stream waits for what
     // the caller's stream has queued so far (the strip clear) and the caller's stream later waits for every lane
+    // From here on a failure must not return at once: the lane streams have to be joined onto the caller's stream, the
+    // work sets' `done` events recorded and the pinned read-back slot released, whatever happened in between.  HIP errors
+    // end the batch loop through `chk` and are reported after the join.
+    int result = TRR_OK;
+    auto chk = [&](hipError_t e_, const char* what) {
+        if (e_ == hipSuccess) return true;
+        if (result == TRR_OK || result == TRR_ERR_CANCELLED) result = fail(ctx, TRR_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e_));
+        return false;
+    };
     const bool forked = pool > 1;
     if (forked) {
-        HIPCHK(ctx, hipEventRecord(ctx->fork, st));
-        for (uint32_t k = 0; k < lanes; ++k) HIPCHK(ctx, hipStreamWaitEvent(ctx->ws[(lane_base + k) % pool].stream, ctx->fork, 0));
+        // every lane stream waits for what the caller's stream has queued so far (the strip clear) AND for the previous
+        // user of its work set, which may have been a single-lane frame on another caller stream
+        if (chk(hipEventRecord(ctx->fork, st), "hipEventRecord"))
+            for (uint32_t k = 0; k < lanes; ++k) {
+                trr_ctx::WorkSet& w = ctx->ws[(lane_base + k) % pool];
+                chk(hipStreamWaitEvent(w.stream, ctx->fork, 0), "hipStreamWaitEvent");
+                chk(hipStreamWaitEvent(w.stream, w.done, 0), "hipStreamWaitEvent");
+            }
     } else {
         // one work set, used directly on the caller's stream: order this frame after the set's previous user, which may
         // have been queued on another stream
-        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ws[0].done, 0));
+        chk(hipStreamWaitEvent(st, ctx->ws[0].done, 0), "hipStreamWaitEvent");
     }
 
     uint32_t blocks_done = 0;
-    int result = TRR_OK;
     uint32_t batches_run = 0;
     // lagged delivery: the batch that has been queued but not yet handed to the hook
     struct Queued { bool valid = false; uint32_t first = 0, n = 0, done_after = 0; hipStream_t stream = nullptr; } queued;
@@ -1268,7 +1350,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         if (progress) progress(user, q.done_after, n_owned);
         return TRR_OK;
     };
-    for (uint32_t bi = 0; bi < n_batches; ++bi) {
+    for (uint32_t bi = 0; bi < n_batches && result == TRR_OK; ++bi) {
         if (cancel_flag && *cancel_flag) { result = TRR_ERR_CANCELLED; break; }   // render.rs:113
         trr_ctx::WorkSet& w = ctx->ws[(lane_base + bi % lanes) % pool];
         hipStream_t s_ = forked ? w.stream : st;
@@ -1278,14 +1360,14 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         bp.n_pixels = bp.n_blocks * bpix;
         bp.n_samples = bp.n_pixels * spp;
         bp.cap = cap;
-        HIPCHK(ctx, hipMemsetAsync(w.counters.p, 0, RB_STRIDE, s_));
+        if (!chk(hipMemsetAsync(w.counters.p, 0, RB_STRIDE, s_), "hipMemsetAsync")) break;
         WorkView wv;
         wv.hits = (HitRec*)w.hits.p; wv.level = (float4*)w.level.p; wv.term = (float4*)w.term.p; wv.nlev = (uint8_t*)w.nlev.p; wv.color = (float*)w.color.p;
         wv.occ = (int32_t*)w.occ.p; wv.wqueue = (float4*)w.wqueue.p; wv.gqueue = (float4*)w.gqueue.p; wv.shadow_q = (float4*)w.shadow_q.p;
         wv.chain_q[0] = (float4*)w.chain_q[0].p; wv.chain_q[1] = (float4*)w.chain_q[1].p; wv.counters = w.counters.p; wv.spill = (uint2*)w.spill.p;
         queue_batch(fp, bp, wv, grids, count, strip_dev, ids_obj_dev, ids_tri_dev, s_, ev_begin, ev_end);
-        HIPCHK(ctx, hipGetLastError());
-        if (stats) HIPCHK(ctx, hipMemcpyAsync(pinned_base + rb_stride * bi, w.counters.p, rb_stride, hipMemcpyDeviceToHost, s_));
+        if (!chk(hipGetLastError(), "kernel launch")) break;
+        if (stats && !chk(hipMemcpyAsync(pinned_base + rb_stride * bi, w.counters.p, rb_stride, hipMemcpyDeviceToHost, s_), "hipMemcpyAsync")) break;
         ++batches_run;
         blocks_done += bp.n_blocks;
         if (interactive) {
@@ -1317,16 +1399,17 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
             blocks_done -= queued.n;
         }
     }
-    if (forked) {   // join
+    if (forked) {   // join (also after a failure: whatever was queued on the lanes is ordered before the caller's next work)
         for (uint32_t k = 0; k < lanes; ++k) {
             trr_ctx::WorkSet& w = ctx->ws[(lane_base + k) % pool];
-            HIPCHK(ctx, hipEventRecord(w.done, w.stream));
-            HIPCHK(ctx, hipStreamWaitEvent(st, w.done, 0));
+            if (chk(hipEventRecord(w.done, w.stream), "hipEventRecord")) chk(hipStreamWaitEvent(st, w.done, 0), "hipStreamWaitEvent");
         }
     } else {
-        HIPCHK(ctx, hipEventRecord(ctx->ws[0].done, st));
+        chk(hipEventRecord(ctx->ws[0].done, st), "hipEventRecord");
     }
-    if (stats) {
+    if (stats && result != TRR_OK && result != TRR_ERR_CANCELLED) {
+        ctx->pinned[pinned_slot].in_use = false;   // a failed frame leaves no statistics pending
+    } else if (stats) {
         trr_ctx::PendingStats f;
         f.out = stats;
         f.ev_first = ev_first; f.ev_count = n_events; f.ev_kind = ev_kind;
@@ -1355,6 +1438,8 @@ int trr_render_shard_device(trr_ctx* ctx, trr_scene* scene, float delta, uint32_
                             uint32_t n_shards, void* strip_dev, size_t strip_bytes, void* stream,
                             const volatile int32_t* cancel_flag, trr_progress_cb progress, void* user, trr_stats* stats_out) {
     if (!ctx) return fail(nullptr, TRR_ERR_INVALID, "trr_render_shard_device: ctx is NULL");
+    if (is_multi(ctx)) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device: a multi-device context shards by itself (use trr_render / trr_render_blocks)");
+    DeviceGuard guard;
     return render_shard_impl(ctx, scene, delta, max_depth, flags, shard, n_shards, (uint8_t*)strip_dev, strip_bytes,
                              stream ? (hipStream_t)stream : ctx->stream, nullptr, nullptr, cancel_flag, progress, user, stats_out);
 }
@@ -1395,6 +1480,8 @@ size_t trr_noalloc_scratch_bytes(void) { return SCRATCH_BYTES; }
 int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t max_depth, uint32_t shard, uint32_t n_shards,
                                     void* strip_dev, size_t strip_bytes, void* stream) {
     if (!ctx || !sc) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: NULL context or scene");
+    if (is_multi(ctx)) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: needs a single-device context");
+    DeviceGuard guard;
     if (sc->ctx != ctx) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: scene belongs to another context");
     if (!sc->have_camera || !sc->have_settings) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: camera/settings not set");
     if (!(delta >= 0.0f)) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: delta must be >= 0");
@@ -1469,6 +1556,8 @@ int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, ui
 int trr_assemble_device(trr_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_shards, const void* strips_dev, void* frame_dev,
                         void* stream) {
     if (!ctx || !strips_dev || !frame_dev) return fail(ctx, TRR_ERR_INVALID, "trr_assemble_device: NULL argument");
+    if (is_multi(ctx)) ctx = ctx->subs[0];   // the root device assembles
+    DeviceGuard guard;
     Tiling t;
     if (n_shards == 0) return fail(ctx, TRR_ERR_INVALID, "trr_assemble_device: n_shards is 0");
     if (!tiling_of(width, height, &t)) return fail(ctx, TRR_ERR_RESOLUTION, "trr_assemble_device: width and height must be >= 20");
@@ -1486,6 +1575,24 @@ int trr_render_blocks(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_
     const uint32_t w = scene->camera.width, h = scene->camera.height;
     Tiling t;
     if (!tiling_of(w, h, &t)) return fail(ctx, TRR_ERR_RESOLUTION, "trr_render_blocks: width and height must be >= 20 (render.rs:109)");
+    DeviceGuard guard;
+    if (is_multi(ctx) && ctx->subs.size() > 1) {
+        // several devices: the blocks of a frame finish within a few milliseconds of each other on different devices, so
+        // the whole frame is rendered (cancel / progress polled per batch) and its blocks are then handed over in row-major
+        // order, each exactly once, on the calling thread
+        std::vector<uint8_t> frame((size_t)w * h * 3), block((size_t)t.bw * t.bh * 3);
+        int rres = multi_render(ctx, scene, delta, max_depth, flags & ~(TRR_FLAG_DEFER_STATS | TRR_FLAG_PIPELINED), frame.data(), cancel_flag,
+                                progress, user, stats_out);
+        if (rres != TRR_OK) return rres;   // a cancelled frame delivers nothing: its blocks are not known to be final
+        for (uint32_t b = 0; b < t.nblocks; ++b) {
+            const uint32_t xb = b % t.nbx, yb = b / t.nbx;
+            for (uint32_t y = 0; y < t.bh; ++y)
+                std::memcpy(block.data() + (size_t)y * t.bw * 3, frame.data() + ((size_t)(yb * t.bh + y) * w + (size_t)xb * t.bw) * 3, (size_t)t.bw * 3);
+            sink(user, xb, yb, t.bw, t.bh, block.data());
+        }
+        return TRR_OK;
+    }
+    if (is_multi(ctx)) { ctx = ctx->subs[0]; scene = scene->replicas[0]; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t sb = trr_strip_bytes(w, h, 1), block_bytes = (size_t)t.bw * t.bh * 3;
     int rc;
@@ -1518,6 +1625,14 @@ int trr_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, 
                void* user, trr_stats* stats_out) {
     if (!ctx || !scene || !rgb_out) return fail(ctx, TRR_ERR_INVALID, "trr_render: NULL argument");
     if (!scene->have_camera) return fail(ctx, TRR_ERR_INVALID, "trr_render: camera not set");
+    DeviceGuard guard;
+    if (is_multi(ctx)) {
+        if (hit_obj_out || hit_tri_out) {
+            if (ctx->subs.size() > 1) return fail(ctx, TRR_ERR_INVALID, "trr_render: hit-id buffers need a single-device context");
+            return trr_render(ctx->subs[0], scene->replicas[0], delta, max_depth, flags, rgb_out, hit_obj_out, hit_tri_out, cancel_flag, progress, user, stats_out);
+        }
+        return multi_render(ctx, scene, delta, max_depth, flags & ~(TRR_FLAG_DEFER_STATS | TRR_FLAG_PIPELINED), rgb_out, cancel_flag, progress, user, stats_out);
+    }
     const uint32_t w = scene->camera.width, h = scene->camera.height;
     Tiling t;
     if (!tiling_of(w, h, &t)) return fail(ctx, TRR_ERR_RESOLUTION, "trr_render: width and height must be >= 20 (render.rs:109)");
@@ -1549,3 +1664,237 @@ int trr_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, 
 
 }   // extern "C"
 
+// ---- multi-device contexts --------------------------------------------------------------------------------------------------
+// One process, one render thread (the reference's host: render.rs:39-71, statusbar.rs:142-157) and N GPUs: the context owns a
+// plain context per device, every scene is uploaded to each of them, a frame's blocks are dealt round-robin (block id % N ==
+// device index, interleaved so that sky / object imbalance averages out), every device renders its blocks into a compact strip
+// and ONE ncclGather (RCCL over xGMI) brings the strips to the first device, which de-interleaves them into the frame.
+// RCCL is loaded on demand (dlopen), so that a single-GPU host -- and the static archive a build.rs links -- needs no librccl.
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Gather)(const void* send, void* recv, size_t count, int datatype, int root, void* comm, hipStream_t stream) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+constexpr int kNcclUint8 = 1;   // ncclDataType_t (rccl.h)
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the copy a host process already holds (PyTorch-ROCm bundles one) first, so that one RCCL serves the whole process
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names)
+            if ((r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        for (const char* n : names) {
+            if (r.handle) break;
+            r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!r.handle) { r.error = std::string("RCCL is not loadable: ") + dlerror(); return; }
+        auto sym = [&](const char* name) {
+            void* p = dlsym(r.handle, name);
+            if (!p && r.error.empty()) r.error = std::string("RCCL lacks ") + name;
+            return p;
+        };
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Gather = (decltype(r.Gather))sym("ncclGather");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    });
+    return &r;
+}
+}   // namespace
+
+static void multi_destroy(trr_ctx* ctx) {
+    Rccl* r = rccl();
+    for (void* c : ctx->comms)
+        if (c && r->CommDestroy) (void)r->CommDestroy(c);
+    if (!ctx->subs.empty()) {
+        (void)hipSetDevice(ctx->subs[0]->device);
+        release(ctx->gathered);
+    }
+    for (trr_ctx* c : ctx->subs) trr_destroy(c);
+    delete ctx;
+}
+
+static int multi_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_objects, const trr_image_rgb8* textures,
+                              uint32_t n_textures, uint32_t build, trr_scene** out) {
+    trr_scene* sc = new trr_scene();
+    sc->ctx = ctx;
+    sc->device = ctx->subs[0]->device;
+    // replicated scene: the same upload on every device (devices build / receive their copies one after the other)
+    for (trr_ctx* c : ctx->subs) {
+        trr_scene* r = nullptr;
+        int rc = trr_scene_create_ex(c, objects, n_objects, textures, n_textures, build, &r);
+        if (rc != TRR_OK) {
+            std::string msg = c->err;
+            trr_scene_destroy(sc);
+            return fail(ctx, rc, msg);
+        }
+        sc->replicas.push_back(r);
+    }
+    sc->n_objs = n_objects;
+    *out = sc;
+    return TRR_OK;
+}
+
+// One frame on all devices of the context: shard renders (one host thread per device while cancel / progress need polling,
+// plain asynchronous queueing otherwise), one gather, assemble and read-back on the first device.
+static int multi_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t flags, uint8_t* rgb_out,
+                        const volatile int32_t* cancel_flag, trr_progress_cb progress, void* user, trr_stats* stats_out) {
+    if (scene->ctx != ctx || scene->replicas.size() != ctx->subs.size()) return fail(ctx, TRR_ERR_INVALID, "render: scene belongs to another context");
+    const uint32_t n = (uint32_t)ctx->subs.size();
+    const uint32_t w = scene->camera.width, h = scene->camera.height;
+    Tiling t;
+    if (!tiling_of(w, h, &t)) return fail(ctx, TRR_ERR_RESOLUTION, "trr_render: width and height must be >= 20 (render.rs:109)");
+    const auto wall0 = std::chrono::steady_clock::now();
+    const size_t sb = trr_strip_bytes(w, h, n), fb = (size_t)w * h * 3;
+    trr_ctx* root = ctx->subs[0];
+    int rc;
+    for (trr_ctx* c : ctx->subs) {
+        HIPCHK(ctx, hipSetDevice(c->device));
+        if ((rc = ensure(c, c->strip, sb))) return fail(ctx, rc, c->err);
+    }
+    HIPCHK(ctx, hipSetDevice(root->device));
+    if ((rc = ensure(root, root->frame, fb))) return fail(ctx, rc, root->err);
+    const bool use_rccl = n > 1 || std::getenv("TRR_MULTI_FORCE_RCCL") != nullptr;
+    if (use_rccl) {
+        if ((rc = ensure(root, ctx->gathered, sb * n))) return fail(ctx, rc, root->err);
+        if (ctx->comms.empty()) {
+            Rccl* r = rccl();
+            if (!r->error.empty()) return fail(ctx, TRR_ERR_DEVICE, r->error);
+            std::vector<int> devs;
+            for (trr_ctx* c : ctx->subs) devs.push_back(c->device);
+            std::vector<void*> comms(n, nullptr);
+            int e = r->CommInitAll(comms.data(), (int)n, devs.data());
+            if (e != 0) return fail(ctx, TRR_ERR_DEVICE, std::string("ncclCommInitAll: ") + r->GetErrorString(e));
+            ctx->comms = comms;
+        }
+    }
+
+    // ---- shard renders ----
+    std::vector<trr_stats> st(n);
+    std::vector<int> res(n, TRR_OK);
+    const bool polled = cancel_flag != nullptr || progress != nullptr;
+    std::mutex mu;
+    std::vector<uint32_t> done(n, 0);
+    struct ProgressCtx { std::mutex* mu; std::vector<uint32_t>* done; uint32_t dev, total; trr_progress_cb cb; void* user; };
+    auto on_progress = +[](void* u, uint32_t blocks_done, uint32_t) {
+        ProgressCtx* p = static_cast<ProgressCtx*>(u);
+        std::lock_guard<std::mutex> lock(*p->mu);   // the caller's callback runs on one thread at a time (render.rs:143-149)
+        (*p->done)[p->dev] = blocks_done;
+        uint32_t sum = 0;
+        for (uint32_t v : *p->done) sum += v;
+        p->cb(p->user, sum, p->total);
+    };
+    std::vector<ProgressCtx> pc(n);
+    auto render_one = [&](uint32_t d) {
+        trr_ctx* c = ctx->subs[d];
+        if (hipSetDevice(c->device) != hipSuccess) { res[d] = fail(c, TRR_ERR_DEVICE, "hipSetDevice failed"); return; }
+        pc[d] = ProgressCtx{&mu, &done, d, t.nblocks, progress, user};
+        res[d] = render_shard_impl(c, scene->replicas[d], delta, max_depth, flags, d, n, (uint8_t*)c->strip.p, sb, c->stream, nullptr, nullptr,
+                                   cancel_flag, progress ? on_progress : nullptr, &pc[d], stats_out ? &st[d] : nullptr);
+    };
+    if (polled && n > 1) {
+        std::vector<std::thread> th;
+        for (uint32_t d = 0; d < n; ++d) th.emplace_back(render_one, d);
+        for (auto& x : th) x.join();
+    } else {
+        for (uint32_t d = 0; d < n; ++d) render_one(d);
+    }
+    int result = TRR_OK;
+    for (uint32_t d = 0; d < n; ++d)
+        if (res[d] != TRR_OK && res[d] != TRR_ERR_CANCELLED) return fail(ctx, res[d], ctx->subs[d]->err);
+        else if (res[d] == TRR_ERR_CANCELLED) result = TRR_ERR_CANCELLED;
+
+    // ---- the single exchange of the path: finished RGB8 strips to the first device ----
+    const void* strips = root->strip.p;
+    if (use_rccl) {
+        Rccl* r = rccl();
+        int e = r->GroupStart();
+        for (uint32_t d = 0; d < n && e == 0; ++d) {
+            trr_ctx* c = ctx->subs[d];
+            if (hipSetDevice(c->device) != hipSuccess) return fail(ctx, TRR_ERR_DEVICE, "hipSetDevice failed");
+            e = r->Gather(c->strip.p, d == 0 ? ctx->gathered.p : nullptr, sb, kNcclUint8, 0, ctx->comms[d], c->stream);
+        }
+        int e2 = r->GroupEnd();
+        if (e == 0) e = e2;
+        if (e != 0) return fail(ctx, TRR_ERR_DEVICE, std::string("ncclGather: ") + r->GetErrorString(e));
+        strips = ctx->gathered.p;
+    }
+    HIPCHK(ctx, hipSetDevice(root->device));
+    launch_assemble(root->stream, w, h, t.bw, t.bh, t.nbx, t.nby, n, sb, (const uint8_t*)strips, (uint8_t*)root->frame.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(rgb_out, root->frame.p, fb, hipMemcpyDeviceToHost, root->stream));
+    HIPCHK(ctx, hipStreamSynchronize(root->stream));
+    for (uint32_t d = 1; d < n; ++d) {   // the other devices' gather sends have completed with the root's receive; make it explicit
+        HIPCHK(ctx, hipSetDevice(ctx->subs[d]->device));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->subs[d]->stream));
+    }
+    if (stats_out) {
+        trr_stats sum{};
+        for (const trr_stats& a : st) {
+            sum.rays_primary += a.rays_primary; sum.rays_shadow += a.rays_shadow; sum.rays_reflection += a.rays_reflection;
+            sum.rays_march += a.rays_march; sum.node_visits += a.node_visits; sum.tri_tests += a.tri_tests; sum.box_tests += a.box_tests;
+            sum.ms_trace += a.ms_trace; sum.ms_shade += a.ms_shade; sum.trace_launches += a.trace_launches;
+            sum.blocks_rendered += a.blocks_rendered; sum.wave_node_steps += a.wave_node_steps; sum.wave_tri_steps += a.wave_tri_steps;
+            sum.wave_outer_steps += a.wave_outer_steps; sum.wave_lane_steps += a.wave_lane_steps; sum.wave_trans_steps += a.wave_trans_steps;
+            sum.trans_lanes += a.trans_lanes; sum.wave_uniform_node_steps += a.wave_uniform_node_steps; sum.queue_overflows += a.queue_overflows;
+        }
+        sum.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        *stats_out = sum;
+    }
+    if (result == TRR_ERR_CANCELLED) return fail(ctx, result, "render cancelled");
+    return TRR_OK;
+}
+
+extern "C" {
+
+int trr_create_multi(const int* device_ids, int n_devices, trr_ctx** out) {
+    if (!out) return fail(nullptr, TRR_ERR_INVALID, "trr_create_multi: out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices <= 0 || n_devices > 64) return fail(nullptr, TRR_ERR_INVALID, "trr_create_multi: need 1..64 device ids");
+    for (int a = 0; a < n_devices; ++a)
+        for (int b = a + 1; b < n_devices; ++b)
+            if (device_ids[a] == device_ids[b]) return fail(nullptr, TRR_ERR_INVALID, "trr_create_multi: a device is listed twice");
+    DeviceGuard guard;
+    trr_ctx* ctx = new trr_ctx();
+    ctx->device = device_ids[0];
+    for (int k = 0; k < n_devices; ++k) {
+        trr_ctx* c = nullptr;
+        int rc = trr_create(device_ids[k], &c);
+        if (rc != TRR_OK) {
+            std::string msg = g_tls_error;
+            for (trr_ctx* x : ctx->subs) trr_destroy(x);
+            delete ctx;
+            return fail(nullptr, rc, msg);
+        }
+        ctx->subs.push_back(c);
+    }
+    ctx->n_cu = ctx->subs[0]->n_cu;
+    ctx->desc = std::to_string(n_devices) + " x " + ctx->subs[0]->desc;
+    *out = ctx;
+    return TRR_OK;
+}
+
+int trr_device_count(const trr_ctx* ctx) {
+    if (!ctx) return 0;
+    return ctx->subs.empty() ? 1 : (int)ctx->subs.size();
+}
+
+uint32_t trr_shard_blocks(uint32_t width, uint32_t height, uint32_t shard, uint32_t n_shards, uint32_t* block_ids, uint32_t capacity) {
+    Tiling t;
+    if (n_shards == 0 || shard >= n_shards || !tiling_of(width, height, &t)) return 0;
+    const uint32_t n = owned_blocks(t, shard, n_shards);
+    for (uint32_t j = 0; j < n && j < capacity && block_ids; ++j) block_ids[j] = shard + j * n_shards;   // the j-th owned block
+    return n;
+}
+
+}   // extern "C"

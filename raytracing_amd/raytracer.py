@@ -62,12 +62,23 @@ def _camera_desc(cam) -> N.CameraDesc:
 
 
 class Context:
-    """One GPU of this process (trr_ctx)."""
+    """One GPU of this process (trr_create), or -- ``devices=[...]`` -- several behind one context (trr_create_multi): scenes
+    are then replicated, ``render_frame`` / ``render_blocks`` shard the block grid over the devices and gather the strips
+    with one ncclGather inside the library."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, devices=None):
         self._h = C.c_void_p()
-        N.check(N.lib().trr_create(int(device), C.byref(self._h)))
-        self.device = int(device)
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            N.check(N.lib().trr_create_multi(C.addressof(ids), len(devices), C.byref(self._h)))
+            self.device = int(devices[0])
+        else:
+            N.check(N.lib().trr_create(int(device), C.byref(self._h)))
+            self.device = int(device)
+
+    @property
+    def device_count(self) -> int:
+        return int(N.lib().trr_device_count(self._h))
 
     @property
     def handle(self):

@@ -175,3 +175,26 @@ def test_cpp_host_header_compiles_standalone(tmp_path):
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     p = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, src], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
+
+
+def test_shard_partition_of_the_library_at_8_devices():
+    """trr_shard_blocks (the partition a multi-device context and the rank-per-GPU path both use) at n = 8: every block of
+    the 20x20 grid (render.rs:109-110) is owned exactly once, in strip order, and agrees with the numpy restatement."""
+    import ctypes as C
+    from raytracing_amd import _native as N
+    from raytracing_amd import multigpu
+    L = N.lib()
+    for (w, h) in [(3840, 2160), (1920, 1080), (810, 610), (50, 47)]:
+        bw, bh, nbx, nby = multigpu.tiling(w, h)
+        for n in (1, 2, 3, 8):
+            seen = []
+            for shard in range(n):
+                cnt = L.trr_shard_blocks(w, h, shard, n, None, 0)
+                ids = (C.c_uint32 * max(1, cnt))()
+                assert L.trr_shard_blocks(w, h, shard, n, C.addressof(ids), cnt) == cnt
+                got = list(ids)[:cnt]
+                assert got == multigpu.owned_blocks(w, h, shard, n)
+                assert cnt * bw * bh * 3 <= L.trr_strip_bytes(w, h, n) == multigpu.strip_bytes(w, h, n)
+                seen += got
+            assert sorted(seen) == list(range(nbx * nby))
+    assert L.trr_shard_blocks(19, 40, 0, 1, None, 0) == 0 and L.trr_shard_blocks(100, 100, 2, 2, None, 0) == 0
