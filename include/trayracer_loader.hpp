@@ -275,7 +275,8 @@ inline std::string rest_after_keyword(const std::string& line) {
 // current group and object (an object that never received a group is dropped); `g` closes the current group and starts a
 // new one WITHOUT a material; `usemtl` on a group that has a material closes it and continues in a copy, on a group
 // without one it sets the material of the whole group (faces already in it included); `mtllib`: the rest of the line,
-// words re-joined by single spaces, is ONE library; `s`, `l` and unknown directives are ignored.
+// words re-joined by single spaces, is ONE library; `s` and `l` are ignored, any other directive is an error (the crate's
+// ObjError::UnexpectedCommand: a git-LFS pointer stub in place of a mesh fails the load; [crate], parity unpinned).
 inline ObjData parse_obj(const std::string& text) {
     ObjData d;
     ObjObject obj{"default", {}};
@@ -339,6 +340,8 @@ inline ObjData parse_obj(const std::string& text) {
             std::string name = w[1];
             for (size_t k = 2; k < w.size(); ++k) name += " " + w[k];
             d.material_libs.push_back(name);
+        } else if (key != "s" && key != "l") {
+            throw LoadError("line " + std::to_string(no) + ": unexpected command '" + key + "'");
         }
     }
     if (group) obj.groups.push_back(std::move(*group));

@@ -117,7 +117,9 @@ def parse_obj(text: str) -> ObjData:
     * ``usemtl`` on a group that already has a material closes it and continues in a copy with ``index + 1``; on a group
       WITHOUT a material it sets the material of the whole group, faces already in it included;
     * ``mtllib``: the rest of the line, words re-joined by single spaces, is ONE library name;
-    * ``s`` and ``l`` are ignored.  Unknown directives are ignored here (the crate's strictness is unpinned).
+    * ``s`` and ``l`` are ignored; any other directive is an error (the crate's ``ObjError::UnexpectedCommand``), which is
+      how a git-LFS pointer stub in place of a mesh ("version https://git-lfs...") fails the load of the whole scene
+      (scene/mod.rs:78-96).  [crate], parity unpinned.
     """
     pos: List[List[float]] = []
     tex: List[List[float]] = []
@@ -176,7 +178,10 @@ def parse_obj(text: str) -> ObjData:
             if not args:
                 raise SceneLoadError(f"line {no}: mtllib without a file name")
             libs.append(" ".join(args))
-        # "s", "l" and anything else: ignored
+        elif key in ("s", "l"):
+            pass
+        else:
+            raise SceneLoadError(f"line {no}: unexpected command '{key}'")
     if group is not None:
         obj.groups.append(group)
     objects.append(obj)
