@@ -48,6 +48,21 @@ static void write_png(const std::string& path, const Image& im) {
 }
 
 int main(int argc, char** argv) {
+    // trr_cli --decode-image <in> <out.ppm>: what image::open(in)?.into_rgb8() (object.rs:31-38) yields, as a binary PPM
+    if (argc == 4 && std::string(argv[1]) == "--decode-image") {
+        try {
+            const Image im = loader::load_image_rgb8(argv[2]);
+            FILE* f = std::fopen(argv[3], "wb");
+            if (!f) { std::fprintf(stderr, "error: cannot write %s\n", argv[3]); return 2; }
+            std::fprintf(f, "P6\n%u %u\n255\n", im.width, im.height);
+            std::fwrite(im.rgb.data(), 1, im.rgb.size(), f);
+            std::fclose(f);
+            return 0;
+        } catch (const loader::LoadError& e) {
+            std::fprintf(stderr, "error: %s\n", e.what());
+            return 2;
+        }
+    }
     std::string scene_path, out = "render.png", dump;
     int device = 0;
     long width = 0, height = 0, samples = -1;

@@ -15,9 +15,11 @@
 // ([crate] below) -- PARITY UNPINNED for grammar corner cases, like the Python loader.  The YAML reader covers the subset
 // the reference's serializer emits and people write by hand for this schema: block and flow mappings and sequences,
 // plain / quoted scalars, comments, the tags !Color / !Path; no anchors, no multi-line scalars.
-// Images: 8-bit non-interlaced PNG (all colour types) and binary PPM decode here; JPEG / TIFF / EXR do not (a texture
-// that fails to load only warns, object.rs:92-96; a skybox that fails makes extraArgs fall back to the defaults,
-// mod.rs:100-110).
+// Images: 8-bit non-interlaced PNG (all colour types) and binary PPM decode here, TIFF (strips, 8-bit; none / LZW /
+// PackBits) and baseline JPEG in trayracer_image.hpp -- the formats of the reference's own test textures
+// (res/test/textures/).  OpenEXR does not decode (the reference's EXR skyboxes are git-LFS stubs: nothing to pin a decoder
+// against).  A texture that fails to load only warns (object.rs:92-96); a skybox that fails makes extraArgs fall back to
+// the defaults (mod.rs:100-110).
 #pragma once
 
 #include <zlib.h>
@@ -34,6 +36,7 @@
 #include <sstream>
 
 #include "trayracer.hpp"
+#include "trayracer_image.hpp"
 
 namespace trayracer {
 namespace loader {
@@ -171,8 +174,19 @@ inline Image load_image_rgb8(const std::string& path) {
     try {
         d = read_file(path);
         if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') return decode_ppm(d);
+        const bool is_tiff = d.size() >= 4 && ((d[0] == 'I' && d[1] == 'I' && d[2] == 42 && d[3] == 0) || (d[0] == 'M' && d[1] == 'M' && d[2] == 0 && d[3] == 42));
+        const bool is_jpeg = d.size() >= 3 && (unsigned char)d[0] == 0xFF && (unsigned char)d[1] == 0xD8;
+        if (is_tiff || is_jpeg) {
+            imgdec::Rgb8 r = is_tiff ? imgdec::tiff::decode(d) : imgdec::jpeg::decode(d);
+            Image im;
+            im.width = r.width; im.height = r.height;
+            im.rgb = std::move(r.rgb);
+            return im;
+        }
         return decode_png(d);
     } catch (const LoadError& e) {
+        throw LoadError("Failed to load image from path: " + path + ": " + e.what());
+    } catch (const imgdec::DecodeError& e) {
         throw LoadError("Failed to load image from path: " + path + ": " + e.what());
     }
 }

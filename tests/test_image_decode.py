@@ -1,0 +1,119 @@
+"""The C++ loader's TIFF / baseline-JPEG decoders (include/trayracer_image.hpp, driven through examples/trr_cli
+--decode-image) against Pillow: `image::open(path)?.into_rgb8()` of the reference (scene/object.rs:31-38, skybox.rs:56-63).
+TIFF is lossless: bytes must be equal.  JPEG: within 1 LSB of Pillow (libjpeg-turbo, whose default arithmetic the decoder
+restates; measured: identical) -- parity unpinned against the `image` crate's own decoder.  The reference's five real
+textures (res/test/textures/) are decoded IN PLACE in the build container; synthetic files cover the other code paths."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+PIL = pytest.importorskip("PIL.Image")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "examples", "trr_cli")
+REF_TEX = "/root/reference/res/test/textures"
+
+
+def cpp_decode(path, tmp_path, expect_rc=0):
+    assert os.path.exists(CLI), "examples/trr_cli is built by `make -C raytracing_amd/csrc` (python __graft_entry__.py)"
+    out = os.path.join(str(tmp_path), "decoded.ppm")
+    p = subprocess.run([CLI, "--decode-image", path, out], capture_output=True, text=True, timeout=60)
+    assert p.returncode == expect_rc, p.stdout + p.stderr
+    if expect_rc != 0:
+        return p.stderr
+    raw = open(out, "rb").read()
+    parts = raw.split(b"\n", 3)
+    w, h = (int(x) for x in parts[1].split())
+    return np.frombuffer(parts[3], np.uint8).reshape(h, w, 3)
+
+
+def pillow_rgb(path):
+    return np.asarray(PIL.open(path).convert("RGB"))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_TEX), reason="the reference tree exists in the build container only")
+def test_reference_textures_in_place(tmp_path):
+    files = sorted(f for f in glob.glob(os.path.join(REF_TEX, "**", "*.*"), recursive=True))
+    assert len([f for f in files if f.endswith(".tif")]) == 4 and len([f for f in files if f.endswith(".jpg")]) == 2
+    for f in files:
+        got, want = cpp_decode(f, tmp_path), pillow_rgb(f)
+        assert got.shape == want.shape, f
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        if f.endswith(".tif"):
+            assert d.max() == 0, f"{f}: TIFF decode differs from Pillow"
+        else:
+            assert d.max() <= 1, f"{f}: JPEG decode differs from Pillow by {d.max()}"
+
+
+def _pattern(w, h, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([(xx * 5 + yy * 3) % 256, (xx * 2 + yy * 7 + 40) % 256, (xx * yy) % 256], axis=-1).astype(np.int16)
+    noise = rng.integers(-12, 13, size=(h, w, 3))
+    return np.clip(base + noise, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("compression", ["raw", "tiff_lzw", "packbits"])
+@pytest.mark.parametrize("mode", ["RGB", "L", "RGBA", "P"])
+def test_tiff_variants(tmp_path, compression, mode):
+    img = PIL.fromarray(_pattern(67, 45, 3), "RGB")
+    if mode == "P":
+        img = img.quantize(colors=200)
+    elif mode != "RGB":
+        img = img.convert(mode)
+    path = os.path.join(str(tmp_path), f"t_{mode}_{compression}.tif")
+    img.save(path, compression=compression)
+    assert np.array_equal(cpp_decode(path, tmp_path), pillow_rgb(path))
+
+
+def test_tiff_lzw_with_horizontal_predictor_and_many_strips(tmp_path):
+    img = PIL.fromarray(_pattern(300, 420, 5), "RGB")
+    path = os.path.join(str(tmp_path), "pred.tif")
+    img.save(path, compression="tiff_lzw", tiffinfo={317: 2, 278: 7})   # Predictor 2, 7 rows per strip
+    info = PIL.open(path)
+    assert info.tag_v2.get(317) == 2
+    assert np.array_equal(cpp_decode(path, tmp_path), np.asarray(img))
+
+
+@pytest.mark.parametrize("subsampling", [0, 1, 2])       # 4:4:4, 4:2:2, 4:2:0
+@pytest.mark.parametrize("size", [(64, 48), (37, 23), (17, 130), (8, 8), (1, 1)])
+def test_jpeg_baseline_matches_libjpeg_arithmetic(tmp_path, subsampling, size):
+    img = PIL.fromarray(_pattern(size[0], size[1], 11 + subsampling), "RGB")
+    path = os.path.join(str(tmp_path), "j.jpg")
+    img.save(path, quality=87, subsampling=subsampling)
+    got, want = cpp_decode(path, tmp_path), pillow_rgb(path)
+    assert got.shape == want.shape
+    assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1
+
+
+def test_jpeg_grayscale_low_quality_and_restart_intervals(tmp_path):
+    g = PIL.fromarray(_pattern(90, 70, 21), "RGB").convert("L")
+    p1 = os.path.join(str(tmp_path), "g.jpg")
+    g.save(p1, quality=35)
+    assert np.abs(cpp_decode(p1, tmp_path).astype(np.int16) - pillow_rgb(p1).astype(np.int16)).max() <= 1
+    img = PIL.fromarray(_pattern(123, 77, 22), "RGB")
+    p2 = os.path.join(str(tmp_path), "r.jpg")
+    try:
+        img.save(p2, quality=92, subsampling=2, restart_marker_rows=1)
+    except TypeError:
+        pytest.skip("this Pillow cannot write restart markers")
+    data = open(p2, "rb").read()
+    assert b"\xff\xdd" in data   # DRI
+    assert np.abs(cpp_decode(p2, tmp_path).astype(np.int16) - pillow_rgb(p2).astype(np.int16)).max() <= 1
+
+
+def test_unsupported_files_fail_like_a_failed_image_open(tmp_path):
+    img = PIL.fromarray(_pattern(40, 30, 1), "RGB")
+    prog = os.path.join(str(tmp_path), "prog.jpg")
+    img.save(prog, progressive=True)
+    assert "Failed to load image" in cpp_decode(prog, tmp_path, expect_rc=2)
+    exr = os.path.join(str(tmp_path), "sky.exr")
+    open(exr, "wb").write(b"\x76\x2f\x31\x01" + b"\0" * 64)   # OpenEXR magic
+    assert "Failed to load image" in cpp_decode(exr, tmp_path, expect_rc=2)
+    cut = os.path.join(str(tmp_path), "cut.tif")
+    ok = os.path.join(str(tmp_path), "ok.tif")
+    img.save(ok, compression="tiff_lzw")
+    open(cut, "wb").write(open(ok, "rb").read()[:200])
+    assert "Failed to load image" in cpp_decode(cut, tmp_path, expect_rc=2)

@@ -189,3 +189,22 @@ def test_broken_extra_args_fall_back_to_defaults(tmp_path):
     assert "Failed to deserialize extraArgs" in err
     same_scene(loader.load_scene(y), got)
     assert got.settings.samples == 1 and not got.settings.anti_aliasing
+
+
+def test_tiff_and_jpeg_textures_load_the_same_in_both_loaders(tmp_path):
+    """The formats of the reference's own test textures (res/test/textures/: TIFF with LZW + horizontal predictor, baseline
+    4:2:0 JPEG): the C++ decoders (include/trayracer_image.hpp) and the Python loader (Pillow) yield the same RGB8 bytes."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(4)
+    tex = rng.integers(0, 256, size=(24, 40, 3), dtype=np.uint8)
+    Image.fromarray(tex, "RGB").save(os.path.join(str(tmp_path), "a.tif"), compression="tiff_lzw", tiffinfo={317: 2})
+    smooth = np.clip(np.add.outer(np.arange(33) * 6, np.arange(50) * 4)[..., None] + np.array([0, 40, 90]), 0, 255).astype(np.uint8)
+    Image.fromarray(smooth, "RGB").save(os.path.join(str(tmp_path), "b.jpg"), quality=90, subsampling=2)
+    T._write(tmp_path, "quad.mtl", "newmtl red\nKd 0.8 0.1 0.1\nmap_Kd a.tif\nnewmtl blue\nmap_Kd b.jpg\n")
+    T._write(tmp_path, "quad.obj", "mtllib quad.mtl\nv 0 0 0\nv 1 0 0\nv 1 0 1\nv 0 0 1\nusemtl red\nf 1 2 3\nusemtl blue\nf 1 3 4\n")
+    y = T._write(tmp_path, "c.yaml", T.CONFIG_YAML)
+    got, _ = cpp_load(y, tmp_path)
+    want = loader.load_scene(y)
+    assert np.array_equal(want.objects[0].materials[0].diffuse_texture, tex)
+    assert want.objects[0].materials[1].diffuse_texture.shape == (33, 50, 3)
+    same_scene(want, got)
