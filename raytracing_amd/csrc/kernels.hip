@@ -289,7 +289,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
         // launch's tail are then dealt evenly over all wavefronts by the next launch (a kernel boundary makes them visible
         // for free), instead of each wavefront finishing its own, very unequal, backlog.
         from_q = ca->io.src_q != nullptr;
-        total = from_q ? min(*ca->io.src_n, ca->io.src_cap) : ca->bp.n_samples;
+        total = from_q ? min(*ca->io.src_n, ca->io.src_cap) + (ca->io.src_q2 ? min(*ca->io.src_n2, ca->io.src_cap2) : 0u)
+                       : ca->bp.n_samples;
         chunk_min = ca->io.chunk_min;
         n_waves = gridDim.x * (TRACE_THREADS / 64);
         // chunk (guided self-scheduling): a fraction of what is left per wavefront, between chunk_min and CHUNK_MAX items,
@@ -415,7 +416,9 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
                     const uint32_t take = min(rest, w_end - w_next);
                     const uint32_t idx = w_next + (rank - take_q);
                     if (from_q) {
-                        if (cur == REF_IDLE && rank >= take_q && rank - take_q < take) start_secondary(io.src_q + (size_t)idx * 2u);
+                        const uint32_t n1 = min(*io.src_n, io.src_cap);   // entries of the first source queue
+                        if (cur == REF_IDLE && rank >= take_q && rank - take_q < take)
+                            start_secondary(idx < n1 ? io.src_q + (size_t)idx * 2u : io.src_q2 + (size_t)(idx - n1) * 2u);
                     } else if (cur == REF_IDLE && rank >= take_q && rank - take_q < take) {
                         const uint32_t pix = idx / fp.spp, si = idx - pix * fp.spp;
                         const PixelPos pp = pixel_of(fp, bp, pix);
@@ -658,7 +661,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
                 const uint32_t need = nh * L + ns;
                 // destination: the wavefront's own ring, or -- once it can claim no more work items -- the spill queue of
                 // the launch (one returning atomic per wavefront and set-up)
-                const bool spill = (exhausted || io.spill_always != 0u) && io.spill_q != nullptr;
+                const bool spill = exhausted && io.spill_q != nullptr;
                 float4* dst = io.wqueue + (size_t)wave_global * io.qcap * 2u;
                 uint32_t base = q_tail, mask = io.qcap - 1u;
                 bool room = true;

@@ -18,11 +18,13 @@ struct TraceIO {
     const float4* src_q;          // nullptr: the work items are the batch's camera rays; else queue entries spilled by the launch before
     const uint32_t* src_n;        // number of entries in src_q (device memory, written by the launch before)
     uint32_t src_cap;
+    const float4* src_q2;         // nullable: a second source queue, taken after src_q (levels-then-drain: shadow + chain queues)
+    const uint32_t* src_n2;
+    uint32_t src_cap2;
     float4* spill_q;              // nullable: where a wavefront pushes once it can claim no more work items
     uint32_t* spill_n;
     uint32_t spill_cap;
     uint32_t chunk_min;           // smallest claim of work items per wavefront (>= 1)
-    uint32_t spill_always;        // 1: every push goes to the spill queue (level-synchronous schedule: one launch per level)
     uint32_t* first_obj;          // nullable: id buffers of the camera rays' first closest hits
     uint32_t* first_tri;
     unsigned long long* counters; // kernel counters (device_types.h: KC_*)

@@ -11,12 +11,36 @@
 
         if (node_step) {
             if (cur < REF_LEAF) {
+#ifdef TRR_UNIFORM_SCALAR
+                // experiment (kept out): when every lane of the step stands on the SAME node, fetch it once
+                // through the scalar cache instead of 64 x 112 B through the vector memory path
+                float4 lox, loy, loz, hix, hiy, hiz;
+                uint4 ch;
+                {
+                    const uint32_t cur_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                    if (__ballot(cur == cur_first) == __ballot(true)) {
+                        typedef const float __attribute__((address_space(4))) * cfp;
+                        typedef const uint32_t __attribute__((address_space(4))) * cup;
+                        cfp sf = (cfp)(uintptr_t)(g_nodes + cur_first);
+                        cup su = (cup)(uintptr_t)(g_nodes + cur_first);
+                        lox = make_float4(sf[0], sf[1], sf[2], sf[3]); loy = make_float4(sf[4], sf[5], sf[6], sf[7]);
+                        loz = make_float4(sf[8], sf[9], sf[10], sf[11]); hix = make_float4(sf[12], sf[13], sf[14], sf[15]);
+                        hiy = make_float4(sf[16], sf[17], sf[18], sf[19]); hiz = make_float4(sf[20], sf[21], sf[22], sf[23]);
+                        ch = make_uint4(su[24], su[25], su[26], su[27]);
+                    } else {
+                        const float4* nd = reinterpret_cast<const float4*>(g_nodes + cur);
+                        lox = nd[0]; loy = nd[1]; loz = nd[2]; hix = nd[3]; hiy = nd[4]; hiz = nd[5];
+                        ch = *reinterpret_cast<const uint4*>(nd + 6);
+                    }
+                }
+#else
                 const float4* nd = reinterpret_cast<const float4*>(g_nodes + cur);
                 float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
                 uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
+#endif
 #ifdef TRR_DUMMY_LOAD
                 {   // experiment: one more 16-B load per lane from the node's own cache line (is the L1 / address pipe a limit?)
-                    float4 extra = nd[7];
+                    float4 extra = reinterpret_cast<const float4*>(g_nodes + cur)[7];
                     asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
                 }
 #endif
