@@ -111,7 +111,8 @@ struct trr_scene {
     trr_ctx* ctx = nullptr;
     int device = 0;                      // ctx->device, kept so that trr_scene_destroy does not touch the context
     std::vector<trr_scene*> replicas;    // scene of a multi-device context: one uploaded copy per device, nothing else
-    DevBuf nodes, tris, interp, objs, mats, texs, texels, lights, sky;
+    DevBuf nodes, qnodes, tris, interp, objs, mats, texs, texels, lights, sky;
+    bool quantised = false;              // qnodes holds the 64-B form of every node (kernels.hip: k_quantise_nodes)
     std::vector<ObjRec> h_objs;
     uint32_t n_objs = 0, n_lights = 0, n_mats = 0, n_tex = 0;
     uint64_t n_nodes = 0, n_tris_total = 0, n_tris_live = 0;
@@ -403,6 +404,36 @@ static void fill_obj_matrices(ObjRec& o, const float* fwd_cm, const float* inv_c
 
 // TRR_BUILD_DEVICE: every object's tree is built on the GPU (build_device.hip) into arrays of its own, which are then
 // packed behind one another.  sc->mats is already on the device; fills sc->nodes / tris / interp / h_objs and the counts.
+// The 64-B form of the scene's nodes, made on the device from the exact ones (host- or device-built alike), for the level
+// kernels.  Opt-in (TRR_NODES=quantised): same image bit for bit, four 16-B loads per lane and node step instead of seven,
+// and no faster -- 31.2 against 31.3 ms on the 4K x 16 spp frame, 1.7 % more node visits (profiles/r02o_qnodes*.txt;
+// DESIGN.md section 4).  A scene with a bound that is not finite or beyond 2^20 keeps to its exact nodes regardless.
+static int quantise_scene_nodes(trr_ctx* ctx, trr_scene* sc) {
+    sc->quantised = false;
+    if (sc->n_nodes == 0) return TRR_OK;
+    const char* mode = std::getenv("TRR_NODES");
+    if (!mode || mode[0] != 'q') return TRR_OK;
+    int rc;
+    DevBuf flag;
+    if ((rc = ensure(ctx, sc->qnodes, (size_t)sc->n_nodes * sizeof(QNode4))) != TRR_OK || (rc = ensure(ctx, flag, 256)) != TRR_OK) {
+        release(flag);
+        return rc;
+    }
+    uint32_t bad = 1;
+    hipError_t e = hipMemsetAsync(flag.p, 0, 4, ctx->stream);
+    if (e == hipSuccess) {
+        launch_quantise_nodes(ctx->stream, (const Node4*)sc->nodes.p, (QNode4*)sc->qnodes.p, (uint32_t)sc->n_nodes, (uint32_t*)flag.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release(flag);
+    if (e != hipSuccess) return fail(ctx, TRR_ERR_DEVICE, std::string("quantising the BVH nodes: ") + hipGetErrorString(e));
+    sc->quantised = bad == 0;
+    if (!sc->quantised) release(sc->qnodes);
+    return TRR_OK;
+}
+
 static int build_scene_device(trr_ctx* ctx, trr_scene* sc, const trr_object_desc* objects, uint32_t n_objects,
                               const std::vector<uint32_t>& mat_bases) {
     std::vector<DeviceBuildOut> parts(n_objects);
@@ -668,6 +699,7 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
                                             " entries, the trace kernel holds " + std::to_string(TRACE_STACK_ENTRIES) +
                                             (build == TRR_BUILD_DEVICE ? " (build this scene with TRR_BUILD_HOST)" : ""));
     if (rc == TRR_OK) rc = upload(ctx, sc->objs, sc->h_objs.data(), sc->h_objs.size() * sizeof(ObjRec));
+    if (rc == TRR_OK) rc = quantise_scene_nodes(ctx, sc);
     if (rc != TRR_OK) {
         trr_scene_destroy(sc);
         return rc;
@@ -776,7 +808,7 @@ void trr_scene_destroy(trr_scene* sc) {
     // memory of the device; destroying scenes first is still the documented order)
     (void)hipSetDevice(sc->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&sc->nodes, &sc->tris, &sc->interp, &sc->objs, &sc->mats, &sc->texs, &sc->texels, &sc->lights, &sc->sky})
+    for (DevBuf* b : {&sc->nodes, &sc->qnodes, &sc->tris, &sc->interp, &sc->objs, &sc->mats, &sc->texs, &sc->texels, &sc->lights, &sc->sky})
         release(*b);
     delete sc;
 }
@@ -880,7 +912,7 @@ static FrameParams frame_params_of(const trr_scene* sc, const Tiling& tl, uint32
     const uint32_t spp = aa ? sc->settings.samples : 1u;
     const uint32_t L = sc->n_lights;
     FrameParams fp{};
-    fp.nodes = (const Node4*)sc->nodes.p; fp.tris = (const TriRec*)sc->tris.p; fp.interp = (const InterpRec*)sc->interp.p;
+    fp.nodes = (const Node4*)sc->nodes.p; fp.qnodes = sc->quantised ? (const QNode4*)sc->qnodes.p : nullptr; fp.tris = (const TriRec*)sc->tris.p; fp.interp = (const InterpRec*)sc->interp.p;
     fp.objs = (const ObjRec*)sc->objs.p; fp.mats = (const MatRec*)sc->mats.p; fp.texs = (const TexRec*)sc->texs.p;
     fp.texels = (const uint8_t*)sc->texels.p; fp.lights = (const LightRec*)sc->lights.p;
     fp.n_objs = sc->n_objs; fp.n_lights = L;
@@ -916,11 +948,11 @@ static hipEvent_t get_event(trr_ctx* ctx, size_t i) {
     return ctx->events[i];
 }
 
-// counters block of one batch (uint32 words, cleared by ONE memset): [CW_WORK + i] work counter of the batch's i-th trace
+// counters block of one batch (uint32 words, cleared by ONE memset): [CW_WORK + 8 i ..] work counters (one per XCD segment) of the batch's i-th trace
 // launch (work items claimed), [CW_NSHADOW + lvl] / [CW_NCHAIN + lvl] shadow rays emitted at / chain rays entering level
 // lvl (level-synchronous schedule), [CW_SPILL + k] entries spilled by launch k (persistent schedule); the 64-bit kernel
 // counters (device_types.h KC_*) follow at byte offset CW_WORDS*4.
-enum { CW_WORK = 0, CW_NSHADOW = 288, CW_NCHAIN = 576, CW_SPILL = 864, CW_WORDS = 1024 };
+enum { CW_WORK = 0, CW_WORK_STRIDE = 8, CW_NSHADOW = 2304, CW_NCHAIN = 2592, CW_SPILL = 2880, CW_WORDS = 3200 };
 static constexpr uint32_t MAX_FOLLOWUPS = 7;
 static constexpr size_t RB_STRIDE = CW_WORDS * 4 + 8 * 16;   // per batch: launch / queue counters + up to 16 kernel counters
 static_assert(KC_COUNT <= 16, "kernel counters outgrew the read-back block");
@@ -1055,7 +1087,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
         const uint32_t scap = spill_capacity(g.trace, fp.n_lights);
         const uint32_t n_follow = fp.max_depth == 0u ? 0u : std::min(std::min(g.followups, fp.max_depth), MAX_FOLLOWUPS);
         for (uint32_t k = 0; k <= n_follow; ++k) {
-            tio.work_counter = cw + CW_WORK + k;
+            tio.work_counter = cw + CW_WORK + CW_WORK_STRIDE * k;
             tio.src_q = k == 0 ? nullptr : w.gqueue + (size_t)((k - 1) & 1u) * scap * 2u;
             tio.src_n = k == 0 ? nullptr : cw + CW_SPILL + (k - 1);
             tio.src_cap = scap;
@@ -1110,7 +1142,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
                 d.qcap = queue_capacity(fp.n_lights);
                 d.counters = kc;
                 d.spill = w.spill;
-                d.work_counter = cw + CW_WORK + lvl + 1;
+                d.work_counter = cw + CW_WORK + CW_WORK_STRIDE * (lvl + 1);
                 d.src_q = w.shadow_q; d.src_n = cw + CW_NSHADOW + lvl; d.src_cap = bp.cap * std::max(1u, fp.n_lights);
                 d.src_q2 = w.chain_q[(lvl + 1) & 1]; d.src_n2 = cw + CW_NCHAIN + lvl + 1; d.src_cap2 = bp.cap;
                 d.chunk_min = std::max(1u, g.chunk_min[1]);
@@ -1124,7 +1156,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
             t2.n_shadow = cw + CW_NSHADOW + lvl;
             t2.chain_q = w.chain_q[(lvl + 1) & 1];
             t2.n_chain = cw + CW_NCHAIN + lvl + 1;
-            t2.work_counter = cw + CW_WORK + lvl + 1;
+            t2.work_counter = cw + CW_WORK + CW_WORK_STRIDE * (lvl + 1);
             t2.first_obj = nullptr;
             t2.first_tri = nullptr;
             ev_begin(0, s_);

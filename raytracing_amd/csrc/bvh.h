@@ -24,6 +24,19 @@ struct alignas(128) Node4 {
 };
 static_assert(sizeof(Node4) == 128, "Node4 must be one cache line");
 
+// The same node in 64 bytes, what the trace kernels read when the scene allows it (kernels.hip: k_quantise_nodes): the child
+// boxes as 8-bit offsets from the node's own lower corner, in units of a per-axis power of two, rounded OUTWARDS -- child
+// k spans [org + qlo_k * s, org + qhi_k * s] per axis, a superset of its Node4 box.  Byte k of each q word is child k.
+struct alignas(64) QNode4 {
+    float org[3];
+    float sx;
+    float sy, sz;
+    uint32_t qlox, qloy;
+    uint32_t qloz, qhix, qhiy, qhiz;
+    uint32_t child[4];
+};
+static_assert(sizeof(QNode4) == 64, "QNode4 must be half a cache line");
+
 constexpr uint32_t REF_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t REF_LEAF = 0x80000000u;
 // leaf reference: REF_LEAF | (first_slot << 2) | (count - 1), count in 1..4, first_slot < 2^29

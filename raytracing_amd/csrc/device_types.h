@@ -95,6 +95,7 @@ enum { KC_NODES = 0, KC_BOXES, KC_TRIS, KC_MARCH, KC_WNODE, KC_WTRI, KC_WOUTER, 
 struct FrameParams {
     // scene
     const Node4* nodes;
+    const QNode4* qnodes;     // nullptr: traverse the exact 128-B nodes
     const TriRec* tris;
     const InterpRec* interp;
     const ObjRec* objs;

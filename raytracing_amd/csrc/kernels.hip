@@ -249,6 +249,53 @@ constexpr uint32_t MARCH_CAP = 0xFFFFu;   // raycasts of one transparency march 
                                           // would spin for ever on a ray that cannot advance (zero / NaN direction) -- the
                                           // oracle shares this cap, which 3 276 scene units of glass would be needed to reach
 
+// Work items of a trace launch are claimed per wavefront in chunks (guided self-scheduling: a fraction of what is left
+// per wavefront, between chunk_min and CHUNK_MAX items -- one same-address atomic per chunk).  The list can be cut into
+// WORK_SEGMENTS contiguous segments, one per XCD (workgroups are dealt to the 8 XCDs round-robin, so blockIdx & 7 names
+// the XCD): a wavefront then takes chunks from its own XCD's segment first and from the others' once that is used up, so
+// that an XCD's 4 MB L2 sees ONE image region at a time.  Measured with 8 segments (profiles/r02o_xcd_segments.txt):
+// +3 % on the 4K x 16 spp frame, +20..50 % on small frames (unequal regions, up to 8 failed claims per wavefront at the
+// end) -- L2 locality is not what limits the kernel.  Built with one segment (= one device-wide counter).
+#ifndef TRR_WORK_SEGMENTS
+#define TRR_WORK_SEGMENTS 1
+#endif
+constexpr uint32_t WORK_SEGMENTS = TRR_WORK_SEGMENTS;   // power of two; the host reserves 8 counters per launch
+struct WorkClaim {
+    uint32_t seg, tries, chunk, chunk_min, seg_len, waves_per_seg;   // all wave-uniform
+};
+DEV WorkClaim work_claim_init(uint32_t total, uint32_t n_waves, uint32_t chunk_min) {
+    WorkClaim c;
+    c.seg = blockIdx.x & (WORK_SEGMENTS - 1u);
+    c.tries = 0;
+    c.chunk_min = chunk_min;
+    c.seg_len = (((total + WORK_SEGMENTS - 1u) / WORK_SEGMENTS) + 63u) & ~63u;
+    c.waves_per_seg = max(1u, n_waves / WORK_SEGMENTS);
+    c.chunk = max(chunk_min, min(CHUNK_MAX, c.seg_len / (c.waves_per_seg * CHUNK_DIV)));
+    return c;
+}
+// Claims the wavefront's next range [w_next, w_end) of work items; false once every segment is used up (each wavefront finds
+// that out with at most WORK_SEGMENTS failed claims, its exit condition).
+DEV bool work_claim_next(WorkClaim& c, uint32_t* counters, uint32_t total, uint32_t lane, uint32_t& w_next, uint32_t& w_end) {
+    while (c.tries < WORK_SEGMENTS) {
+        const uint32_t seg_base = c.seg * c.seg_len;
+        if (seg_base < total) {
+            const uint32_t seg_end = min(seg_base + c.seg_len, total);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(counters + c.seg, c.chunk);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base < seg_end - seg_base) {
+                w_next = seg_base + base;
+                w_end = min(w_next + c.chunk, seg_end);
+                c.chunk = max(c.chunk_min, min(CHUNK_MAX, (seg_end - w_end) / (c.waves_per_seg * CHUNK_DIV)));
+                return true;
+            }
+        }
+        c.seg = (c.seg + 1u) & (WORK_SEGMENTS - 1u);
+        c.tries++;
+    }
+    return false;
+}
+
 // The kernel's one argument.  The traversal steps of the loop need four of its scalars (nodes, tris, delta, n_objs); the
 // rest -- some 70 dwords -- is read only by the blocks that start and end rays.  Kept as ordinary kernel arguments they
 // all stay in scalar registers for the whole loop, which overflowed the 102 SGPRs (19 spilled into vector-register lanes,
@@ -277,8 +324,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
     const TriRec* const g_tris = args.fp.tris;
     const float delta = args.fp.delta;
     const uint32_t n_objs = args.fp.n_objs;
+    constexpr bool QN = false;                      // this kernel reads the exact nodes (trace_step.inl)
+    const QNode4* const g_qnodes = nullptr;
+    const float e_ray = 0.0f;
     uint2* my_spill;
-    uint32_t total, chunk_min, n_waves, chunk;
+    uint32_t total, chunk_min;
+    WorkClaim claim;
     bool from_q;
     {
         const TraceArgs* ca = cold_args();
@@ -292,10 +343,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
         total = from_q ? min(*ca->io.src_n, ca->io.src_cap) + (ca->io.src_q2 ? min(*ca->io.src_n2, ca->io.src_cap2) : 0u)
                        : ca->bp.n_samples;
         chunk_min = ca->io.chunk_min;
-        n_waves = gridDim.x * (TRACE_THREADS / 64);
-        // chunk (guided self-scheduling): a fraction of what is left per wavefront, between chunk_min and CHUNK_MAX items,
-        // so that claims are rare while there is plenty of work and fine-grained near the end of the launch
-        chunk = max(chunk_min, min(CHUNK_MAX, total / (n_waves * CHUNK_DIV)));
+        claim = work_claim_init(total, gridDim.x * (TRACE_THREADS / 64), chunk_min);
     }
     // This wavefront's ray queue is a ring of io.qcap entries at io.wqueue + wave_global * io.qcap that only this wavefront
     // reads and writes, so no store has to become visible to another CU inside the launch (per-XCD L2s are not coherent
@@ -313,7 +361,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
     constexpr uint32_t F_FIRST = 1u, F_GHAVE = 2u, F_OHAVE = 4u, F_SKIPBOX = 8u;
     constexpr uint32_t REF_IDLE = 0xFFFFFFFEu;           // never a leaf reference: slots stay below 2^29 - 1 (api.hip)
     uint32_t fl = 0;
-    bool exhausted = false, last_chunk = false;          // wave-uniform
+    bool exhausted = false;                              // wave-uniform
     uint32_t w_next = 0, w_end = 0;                      // wave-uniform: this wavefront's claimed range of camera rays
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 0);      // world ray (origin advances during the march)
     uint32_t r_sample = 0, r_meta = 0;
@@ -404,14 +452,9 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
                 if (rest != 0u && !exhausted) {
                     // camera rays are claimed from the device counter in chunks per wavefront (one same-address atomic per
                     // chunk, not per re-fill: 10^6s of atomics on one word serialise in L2) and dealt to idle lanes
-                    if (w_next >= w_end) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(io.work_counter, chunk);
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        w_next = min(base, total);
-                        w_end = min(base + chunk, total);
-                        if (base + chunk >= total) last_chunk = true;
-                        chunk = max(chunk_min, min(CHUNK_MAX, (total - w_end) / (n_waves * CHUNK_DIV)));
+                    if (w_next >= w_end && !work_claim_next(claim, io.work_counter, total, lane, w_next, w_end)) {
+                        exhausted = true;
+                        w_next = w_end = 0;
                     }
                     const uint32_t take = min(rest, w_end - w_next);
                     const uint32_t idx = w_next + (rank - take_q);
@@ -433,7 +476,6 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
                         sp = 0;
                     }
                     w_next += take;
-                    if (last_chunk && w_next >= w_end) exhausted = true;
                 }
             }
         }
@@ -755,13 +797,14 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
 // Every wavefront does one thing (thin ray start / end blocks, hit set-up with full wavefronts), which makes a ray cheaper
 // than in k_trace; the price is 2 * max_depth + 1 dependent launches per batch, each with a ramp-up and a tail.
 // ------------------------------------------------------------------------------------------------
-template <bool RAYGEN, bool COUNT>
+template <bool RAYGEN, bool COUNT, bool QN>
 __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_level(FrameParams fp, BatchParams bp, LevelIO io) {
     __shared__ uint2 s_stack[STACK_LDS * TRACE_THREADS];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     uint2* my_spill = io.spill + ((size_t)blockIdx.x * TRACE_THREADS + tid) * STACK_SPILL;
     const Node4* const g_nodes = fp.nodes;
+    const QNode4* const g_qnodes = fp.qnodes;
     const TriRec* const g_tris = fp.tris;
     const float delta = fp.delta;
 
@@ -780,10 +823,9 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
     constexpr uint32_t F_FIRST = 1u, F_GHAVE = 2u, F_OHAVE = 4u, F_SKIPBOX = 8u;
     constexpr uint32_t REF_IDLE = 0xFFFFFFFEu;
     uint32_t fl = 0;
-    bool exhausted = false, last_chunk = false;          // wave-uniform
+    bool exhausted = false;                              // wave-uniform
     uint32_t w_next = 0, w_end = 0;                      // wave-uniform: this wavefront's claimed range of work items
-    const uint32_t n_waves = gridDim.x * (TRACE_THREADS / 64);
-    uint32_t chunk = max(64u, min(CHUNK_MAX, total / (n_waves * CHUNK_DIV)));
+    WorkClaim claim = work_claim_init(total, gridDim.x * (TRACE_THREADS / 64), 64u);
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 0);      // world ray (origin advances during the march)
     uint32_t r_out = 0, r_sample = 0, r_meta = 0;
     uint32_t obj_i = 0;
@@ -791,6 +833,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
     uint32_t g_slot = 0, g_obj = 0;
     F3 oo = f3(0, 0, 0), od = f3(0, 0, 0), oi = f3(0, 0, 0);
     float len_d = 1.0f, lim_n = INFINITY, slack_abs = 0.0f;
+    float e_ray = 0.0f;   // QN: how far the quantised boxes are pushed out for this ray (trace_step.inl)
     float o_key = 0;
     uint32_t o_slot = 0, o_tri = 0;
     uint32_t cur = REF_IDLE;
@@ -825,20 +868,14 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
         if (idle != 0ull && !exhausted) {
             int nidle = __popcll(idle);
             if (nidle >= REFILL_MIN) {
-                if (w_next >= w_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(io.work_counter, chunk);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    w_next = min(base, total);
-                    w_end = min(base + chunk, total);
-                    if (base + chunk >= total) last_chunk = true;
-                    chunk = max(64u, min(CHUNK_MAX, (total - w_end) / (n_waves * CHUNK_DIV)));
+                if (w_next >= w_end && !work_claim_next(claim, io.work_counter, total, lane, w_next, w_end)) {
+                    exhausted = true;
+                    w_next = w_end = 0;
                 }
                 const uint32_t take = min((uint32_t)nidle, w_end - w_next);
                 uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 uint32_t idx = w_next + rank;
                 w_next += take;
-                if (last_chunk && w_next >= w_end) exhausted = true;
                 if (cur == REF_IDLE && rank < take) {
                     if (RAYGEN) {
                         uint32_t pix = idx / fp.spp, si = idx - pix * fp.spp;
@@ -987,6 +1024,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
                 slack_abs = ob->slack_abs;
                 lim_n = t_lim * len_d + slack_abs;
                 if (!(lim_n == lim_n)) lim_n = INFINITY;
+                // QN: 2^-20 of (largest |origin coordinate| + largest |scene coordinate|, which is slack_abs * 1e4)
+                if (QN) e_ray = 0x1p-20f * rmax(rmax(fabsf(oo.x), fabsf(oo.y)), fabsf(oo.z)) + 0x1p-6f * slack_abs;
                 fl = (fl & ~(F_OHAVE | F_SKIPBOX)) | ((ob->flags & 1u) ? F_SKIPBOX : 0u);
                 cur = ob->root;
                 sp = 0;
@@ -1321,6 +1360,69 @@ __global__ void __launch_bounds__(256) k_assemble(uint32_t width, uint32_t heigh
 }
 
 // ------------------------------------------------------------------------------------------------
+// Node4 -> QNode4 (bvh.h), one thread per node, once per scene.  Every child box is rounded outwards onto the node's own
+// 8-bit grid (checked in double precision, in which every quantity here is exact: the grid step is at least 1/254 of the
+// node's extent, so org / step < 2^32).  *flag is set when a node cannot be quantised -- a bound that is not finite or
+// above 2^20 in magnitude -- and the scene then keeps to its exact nodes.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_quantise_nodes(const Node4* __restrict__ nodes, QNode4* __restrict__ out, uint32_t n,
+                                                        uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const Node4 nd = nodes[i];
+    QNode4 q;
+    bool bad = false;
+    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    float org[3], sc[3];
+    for (int a = 0; a < 3; ++a) {
+        const float* lo = a == 0 ? nd.lox : a == 1 ? nd.loy : nd.loz;
+        const float* hi = a == 0 ? nd.hix : a == 1 ? nd.hiy : nd.hiz;
+        float lo_min = INFINITY, hi_max = -INFINITY;
+        for (int k = 0; k < 4; ++k) {
+            if (nd.child[k] == REF_EMPTY) continue;
+            if (!(fabsf(lo[k]) <= 0x1p20f) || !(fabsf(hi[k]) <= 0x1p20f)) bad = true;   // also catches NaN
+            lo_min = fminf(lo_min, lo[k]);
+            hi_max = fmaxf(hi_max, hi[k]);
+        }
+        if (!(lo_min <= hi_max)) { lo_min = 0.0f; hi_max = 0.0f; }   // no child (or nothing sane): everything below is moot
+        const double ext = (double)hi_max - (double)lo_min;
+        int e2 = -100;   // step 2^e2, at least 2^-100
+        if (ext > 0.0) {
+            int ex;
+            (void)frexp(ext / 254.0, &ex);   // ext / 254 = m * 2^ex, m in [0.5, 1)  ->  2^ex >= ext / 254
+            e2 = max(ex, -100);
+        }
+        double step = ldexp(1.0, e2);
+        while (ceil(ext / step) > 255.0) step *= 2.0;   // (never taken; guards the rounding of the line above)
+        org[a] = lo_min;
+        sc[a] = (float)step;
+        for (int k = 0; k < 4; ++k) {
+            uint32_t l = 255u, h = 0u;   // an unused slot: inverted, and its reference is REF_EMPTY anyway
+            if (nd.child[k] != REF_EMPTY && !bad) {
+                const double dl = floor(((double)lo[k] - (double)lo_min) / step), dh = ceil(((double)hi[k] - (double)lo_min) / step);
+                l = (uint32_t)fmin(fmax(dl, 0.0), 255.0);
+                h = (uint32_t)fmin(fmax(dh, 0.0), 255.0);
+                if ((double)lo_min + l * step > (double)lo[k] || (double)lo_min + h * step < (double)hi[k]) bad = true;   // cannot happen
+            }
+            qlo[a] |= l << (8 * k);
+            qhi[a] |= h << (8 * k);
+        }
+    }
+    q.org[0] = org[0]; q.org[1] = org[1]; q.org[2] = org[2];
+    q.sx = sc[0]; q.sy = sc[1]; q.sz = sc[2];
+    q.qlox = qlo[0]; q.qloy = qlo[1]; q.qloz = qlo[2];
+    q.qhix = qhi[0]; q.qhiy = qhi[1]; q.qhiz = qhi[2];
+    for (int k = 0; k < 4; ++k) q.child[k] = nd.child[k];
+    out[i] = q;
+    if (bad) atomicOr(flag, 1u);
+}
+
+void launch_quantise_nodes(hipStream_t st, const Node4* nodes, QNode4* out, uint32_t n, uint32_t* flag) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_quantise_nodes, dim3((n + 255) / 256), dim3(256), 0, st, nodes, out, n, flag);
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-callable launchers (used by render.cpp)
 // ------------------------------------------------------------------------------------------------
 int trace_blocks_per_cu(bool count) {
@@ -1342,27 +1444,38 @@ void launch_trace(bool count, uint32_t grid, hipStream_t st, const FrameParams& 
     else hipLaunchKernelGGL((k_trace<false>), g, b, 0, st, a);
 }
 
-int level_blocks_per_cu(bool raygen, bool count) {
+// the level kernels read the 64-B quantised nodes when the frame has them (fp.qnodes), the exact ones otherwise
+template <bool QN>
+static int level_blocks_per_cu_t(bool raygen, bool count) {
     int nb = 0;
     hipError_t e;
-    if (raygen) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<true, true>, TRACE_THREADS, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<true, false>, TRACE_THREADS, 0);
-    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<false, true>, TRACE_THREADS, 0)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<false, false>, TRACE_THREADS, 0);
+    if (raygen) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<true, true, QN>, TRACE_THREADS, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<true, false, QN>, TRACE_THREADS, 0);
+    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<false, true, QN>, TRACE_THREADS, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<false, false, QN>, TRACE_THREADS, 0);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
+int level_blocks_per_cu(bool raygen, bool count) {
+    return std::min(level_blocks_per_cu_t<false>(raygen, count), level_blocks_per_cu_t<true>(raygen, count));
+}
 
+template <bool QN>
+static void launch_trace_level_t(bool raygen, bool count, dim3 g, dim3 b, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
+                                 const LevelIO& io) {
+    if (raygen) {
+        if (count) hipLaunchKernelGGL((k_trace_level<true, true, QN>), g, b, 0, st, fp, bp, io);
+        else hipLaunchKernelGGL((k_trace_level<true, false, QN>), g, b, 0, st, fp, bp, io);
+    } else {
+        if (count) hipLaunchKernelGGL((k_trace_level<false, true, QN>), g, b, 0, st, fp, bp, io);
+        else hipLaunchKernelGGL((k_trace_level<false, false, QN>), g, b, 0, st, fp, bp, io);
+    }
+}
 void launch_trace_level(bool raygen, bool count, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
                         const LevelIO& io) {
     dim3 g(grid), b(TRACE_THREADS);
-    if (raygen) {
-        if (count) hipLaunchKernelGGL((k_trace_level<true, true>), g, b, 0, st, fp, bp, io);
-        else hipLaunchKernelGGL((k_trace_level<true, false>), g, b, 0, st, fp, bp, io);
-    } else {
-        if (count) hipLaunchKernelGGL((k_trace_level<false, true>), g, b, 0, st, fp, bp, io);
-        else hipLaunchKernelGGL((k_trace_level<false, false>), g, b, 0, st, fp, bp, io);
-    }
+    if (fp.qnodes != nullptr) launch_trace_level_t<true>(raygen, count, g, b, st, fp, bp, io);
+    else launch_trace_level_t<false>(raygen, count, g, b, st, fp, bp, io);
 }
 
 void launch_setup(bool level0, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp, const SetupIO& io,

@@ -66,6 +66,7 @@ struct ResolveIO {
     const int32_t* occ;
     uint8_t* strip;
 };
+void launch_quantise_nodes(hipStream_t st, const Node4* nodes, QNode4* out, uint32_t n, uint32_t* flag);
 int trace_blocks_per_cu(bool count);
 size_t trace_spill_bytes(uint32_t grid);
 size_t trace_queue_bytes(uint32_t grid, uint32_t qcap);

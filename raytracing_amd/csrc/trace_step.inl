@@ -11,6 +11,56 @@
 
         if (node_step) {
             if (cur < REF_LEAF) {
+                if (COUNT) {
+                    c_nodes++; c_boxes += 4;
+                    const unsigned long long am = __ballot(true);
+                    const uint32_t first_lane = (uint32_t)__ffsll((long long)am) - 1u;
+                    if (lane == first_lane) c_wnode++;
+                    // node steps in which every participating lane stands on the SAME node
+                    const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                    if (__ballot(cur == cur0) == am && lane == first_lane) c_wuni++;
+                }
+                float t0, t1, t2, t3;
+                uint32_t r0, r1, r2, r3;
+                if constexpr (QN) {
+                    // ---- 64-B node (bvh.h QNode4): four 16-B loads per lane instead of seven.  Child k spans
+                    // [org + qlo_k s, org + qhi_k s] per axis, a superset of its exact box; the slab distances come out of
+                    // ONE fused multiply-add per plane, t = q * (s / d) + (org -+ e - o) / d.  That is not the arithmetic of
+                    // the triangle's own-box test below (which stays exact), so every box is pushed out by e = e_ray first:
+                    // 2^-20 of the largest coordinate in play, several times the rounding error of either form, hence a
+                    // near distance never above and a far distance never below what the exact test of anything inside the
+                    // box can compute -- the node test stays a superset test (candidate-set invariant).  1/d is
+                    // clamped to +-2^60 for this test only: beyond that a distance is "never" either way, and the
+                    // products cannot overflow into inf - inf.
+                    const float4* nd = reinterpret_cast<const float4*>(g_qnodes + cur);
+                    const float4 c0 = nd[0], c1 = nd[1], c2 = nd[2];
+                    const uint4 ch = *reinterpret_cast<const uint4*>(nd + 3);
+                    const float ix = __builtin_amdgcn_fmed3f(oi.x, -0x1p60f, 0x1p60f), iy = __builtin_amdgcn_fmed3f(oi.y, -0x1p60f, 0x1p60f),
+                                iz = __builtin_amdgcn_fmed3f(oi.z, -0x1p60f, 0x1p60f);
+                    const float Ax = c0.w * ix, Ay = c1.x * iy, Az = c1.y * iz;
+                    const float dx = c0.x - oo.x, dy = c0.y - oo.y, dz = c0.z - oo.z;
+                    const float Blx = (dx - e_ray) * ix, Bhx = (dx + e_ray) * ix;
+                    const float Bly = (dy - e_ray) * iy, Bhy = (dy + e_ray) * iy;
+                    const float Blz = (dz - e_ray) * iz, Bhz = (dz + e_ray) * iz;
+                    const uint32_t qlx = __float_as_uint(c1.z), qly = __float_as_uint(c1.w), qlz = __float_as_uint(c2.x);
+                    const uint32_t qhx = __float_as_uint(c2.y), qhy = __float_as_uint(c2.z), qhz = __float_as_uint(c2.w);
+#define TRR_QBOX(T, R, K, CH)                                                                                     \
+    {                                                                                                             \
+        float ax = __builtin_fmaf((float)((qlx >> (8 * K)) & 0xFFu), Ax, Blx), bx = __builtin_fmaf((float)((qhx >> (8 * K)) & 0xFFu), Ax, Bhx); \
+        float ay = __builtin_fmaf((float)((qly >> (8 * K)) & 0xFFu), Ay, Bly), by = __builtin_fmaf((float)((qhy >> (8 * K)) & 0xFFu), Ay, Bhy); \
+        float az = __builtin_fmaf((float)((qlz >> (8 * K)) & 0xFFu), Az, Blz), bz = __builtin_fmaf((float)((qhz >> (8 * K)) & 0xFFu), Az, Bhz); \
+        float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));                                        \
+        float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));                                        \
+        bool hit = (tmax > rmax(tmin, 0.0f)) & !(tmin > lim_n);                                                   \
+        T = hit ? tmin : INFINITY;                                                                                \
+        R = hit ? (CH) : REF_EMPTY;                                                                               \
+    }
+                    TRR_QBOX(t0, r0, 0, ch.x)
+                    TRR_QBOX(t1, r1, 1, ch.y)
+                    TRR_QBOX(t2, r2, 2, ch.z)
+                    TRR_QBOX(t3, r3, 3, ch.w)
+#undef TRR_QBOX
+                } else {
 #ifdef TRR_UNIFORM_SCALAR
                 // experiment (kept out): when every lane of the step stands on the SAME node, fetch it once
                 // through the scalar cache instead of 64 x 112 B through the vector memory path
@@ -39,9 +89,15 @@
                 uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
 #endif
 #ifdef TRR_DUMMY_LOAD
-                {   // experiment: one more 16-B load per lane from the node's own cache line (is the L1 / address pipe a limit?)
-                    float4 extra = reinterpret_cast<const float4*>(g_nodes + cur)[7];
-                    asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
+                {   // experiment: TRR_DUMMY_LOAD more 16-B loads per lane from the node's own cache line, through a pointer the
+                    // optimiser cannot see through (is the vector memory path a limit, and how steep is it?)
+                    const float4* xp = reinterpret_cast<const float4*>(g_nodes + cur);
+                    asm volatile("" : "+v"(xp));
+#pragma unroll
+                    for (int k = 0; k < TRR_DUMMY_LOAD; ++k) {
+                        float4 extra = xp[(7 + k) & 7];
+                        asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
+                    }
                 }
 #endif
 #ifdef TRR_DUMMY_VALU
@@ -52,23 +108,12 @@
                     asm volatile("" ::"v"(dv));
                 }
 #endif
-                if (COUNT) {
-                    c_nodes++; c_boxes += 4;
-                    const unsigned long long am = __ballot(true);
-                    const uint32_t first_lane = (uint32_t)__ffsll((long long)am) - 1u;
-                    if (lane == first_lane) c_wnode++;
-                    // node steps in which every participating lane stands on the SAME node
-                    const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-                    if (__ballot(cur == cur0) == am && lane == first_lane) c_wuni++;
-                }
                 // [crate] Ray::intersects_aabb per child, same arithmetic as the per-triangle test below, so a parent
                 // box (exact union of its children) can never reject what a triangle's own box accepts.  Written with
                 // scalars and selects only (no arrays, no short-circuit branches): keeps the step branch-free.
                 // An unused child slot holds the box (+inf .. +inf), which fails the test for every ray; a NaN tmin keeps
                 // the child (NaN > x is false) and simply does not take part in the ordering.
 #define TRR_BOX(T, R, LX, LY, LZ, HX, HY, HZ, CH)                                                          \
-    float T;                                                                                               \
-    uint32_t R;                                                                                            \
     {                                                                                                      \
         float ax = ((LX) - oo.x) * oi.x, bx = ((HX) - oo.x) * oi.x;                                        \
         float ay = ((LY) - oo.y) * oi.y, by = ((HY) - oo.y) * oi.y;                                        \
@@ -84,6 +129,7 @@
                 TRR_BOX(t2, r2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
                 TRR_BOX(t3, r3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
 #undef TRR_BOX
+                }
                 // sort the four (tmin, ref) pairs ascending: 5-comparator network of selects
 #define TRR_CSWAP(TI, RI, TJ, RJ)                                                  \
     {                                                                              \

@@ -1,5 +1,5 @@
 """Counter build of one frame: per-ray and per-wavefront step counts (SIMD efficiency) of the trace kernel.
-Usage: python scripts/experiments/counters.py [config]"""
+Usage: python scripts/experiments/counters.py [config [max_depth]]"""
 import os
 import sys
 
@@ -18,6 +18,8 @@ cfgs = {
     "5": (lambda: standin.standin_mirrors(3840, 2160), 9),
 }
 make, md = cfgs[c]
+if len(sys.argv) > 2:
+    md = int(sys.argv[2])   # e.g. 0: camera rays only
 rt = Raytracer(make(), max_depth=md)
 sb = rt.strip_bytes(1)
 strip = torch.zeros(sb, dtype=torch.uint8, device="cuda")
