@@ -1122,6 +1122,12 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
             sio.level = w.level;
             sio.term = w.term;
             sio.nlev = w.nlev;
+            // 16-B compact shadow entries whenever they can name every light and sample (kernels.hip); TRR_SHADOW=wide keeps
+            // the 32-B ray records (experiments, tests of that path)
+            const char* e_shadow = std::getenv("TRR_SHADOW");
+            const bool wide_shadow = e_shadow && e_shadow[0] == 'w';
+            const uint32_t compact = (!wide_shadow && fp.n_lights <= 128u && bp.cap <= (1u << 25)) ? 1u : 0u;
+            sio.shadow_compact = compact;
             sio.shadow_out = w.shadow_q;
             sio.n_shadow_out = cw + CW_NSHADOW + lvl;
             sio.chain_out = w.chain_q[(lvl + 1) & 1];
@@ -1145,6 +1151,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
                 d.work_counter = cw + CW_WORK + CW_WORK_STRIDE * (lvl + 1);
                 d.src_q = w.shadow_q; d.src_n = cw + CW_NSHADOW + lvl; d.src_cap = bp.cap * std::max(1u, fp.n_lights);
                 d.src_q2 = w.chain_q[(lvl + 1) & 1]; d.src_n2 = cw + CW_NCHAIN + lvl + 1; d.src_cap2 = bp.cap;
+                d.src_compact = compact; d.src_level = lvl;
                 d.chunk_min = std::max(1u, g.chunk_min[1]);
                 ev_begin(0, s_);
                 launch_trace(count, g.trace, s_, fp, bp, d);
@@ -1153,6 +1160,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
             }
             LevelIO t2 = tio;
             t2.shadow_q = w.shadow_q;
+            t2.shadow_compact = compact; t2.shadow_level = lvl;
             t2.n_shadow = cw + CW_NSHADOW + lvl;
             t2.chain_q = w.chain_q[(lvl + 1) & 1];
             t2.n_chain = cw + CW_NCHAIN + lvl + 1;

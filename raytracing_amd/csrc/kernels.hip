@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_types.h"
 #include "launch.h"
@@ -242,7 +243,12 @@ DEV bool candidate_better(bool have, float key, uint32_t tri, float best_key, ui
 // mod.rs:149-153 from the shaded hit of level k; a chain entry of level k >= 1 the reflection ray (P + N*delta,
 // reflect(D, N)) of mod.rs:203-206 from the hit of level k - 1.  The whole ray is in the entry so that a ray STARTS with one
 // memory round trip: the kernel is bound by the latency of dependent loads, not by bytes.
+// Compact shadow entry (16 B, level-synchronous schedule, scenes of at most COMPACT_MAX_LIGHTS lights): (Px Py Pz, sample |
+// light << 25) -- the shaded point itself.  The trace kernel rebuilds the ray of mod.rs:149-153 from it with the very
+// operations the hit set-up would have used (L^ = normalize(light - P), origin = P + L^ * delta), so the same bits; the
+// lights' positions sit in LDS for that.  Halves what the set-up pass writes per hit and what a shadow ray's start reads.
 constexpr uint32_t META_SHADOW = 0x100u;
+constexpr uint32_t COMPACT_MAX_LIGHTS = 128u, COMPACT_SAMPLE_BITS = 25u;
 constexpr uint32_t TRI_FLAG_TRANSPARENT = 1u, TRI_FLAG_REFLECTIVE = 2u;   // TriRec.flags
 constexpr uint8_t NLEV_PENDING = 0xFF;   // nlev of a camera sample whose hit waits for k_setup (max_depth <= 254 keeps it free)
 constexpr uint32_t MARCH_CAP = 0xFFFFu;   // raycasts of one transparency march (mod.rs:100-111); the reference has no cap and
@@ -460,8 +466,27 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
                     const uint32_t idx = w_next + (rank - take_q);
                     if (from_q) {
                         const uint32_t n1 = min(*io.src_n, io.src_cap);   // entries of the first source queue
-                        if (cur == REF_IDLE && rank >= take_q && rank - take_q < take)
-                            start_secondary(idx < n1 ? io.src_q + (size_t)idx * 2u : io.src_q2 + (size_t)(idx - n1) * 2u);
+                        if (cur == REF_IDLE && rank >= take_q && rank - take_q < take) {
+                            if (io.src_compact != 0u && idx < n1) {
+                                // compact shadow entry (levels-then-drain): rebuild the ray of mod.rs:149-153
+                                const float4 a = io.src_q[idx];
+                                const uint32_t wd = __float_as_uint(a.w), l = wd >> COMPACT_SAMPLE_BITS;
+                                const LightRec* lt = fp.lights + l;
+                                const F3 P = f3(a.x, a.y, a.z);
+                                const F3 ld = normalize(f3(lt->pos[0], lt->pos[1], lt->pos[2]) - P);
+                                ro = P + scale(ld, delta);
+                                rd = ld;
+                                r_sample = wd & ((1u << COMPACT_SAMPLE_BITS) - 1u);
+                                r_meta = io.src_level | META_SHADOW | (l << 16);
+                                fl = F_FIRST;
+                                obj_i = 0xFFFFFFFFu;
+                                t_lim = INFINITY;
+                                cur = REF_EMPTY;
+                                sp = 0;
+                            } else {
+                                start_secondary(idx < n1 ? io.src_q + (size_t)idx * 2u : io.src_q2 + (size_t)(idx - n1) * 2u);
+                            }
+                        }
                     } else if (cur == REF_IDLE && rank >= take_q && rank - take_q < take) {
                         const uint32_t pix = idx / fp.spp, si = idx - pix * fp.spp;
                         const PixelPos pp = pixel_of(fp, bp, pix);
@@ -814,6 +839,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
         n_shadow = *io.n_shadow;
         total = n_shadow + *io.n_chain;
     }
+    // compact shadow entries need the lights' positions at every ray start: one LDS read instead of a dependent load
+    __shared__ float s_light_pos[RAYGEN ? 1 : 3 * COMPACT_MAX_LIGHTS];
+    if (!RAYGEN && io.shadow_compact != 0u) {
+        for (uint32_t k = tid; k < 3u * fp.n_lights; k += TRACE_THREADS) s_light_pos[k] = fp.lights[k / 3u].pos[k % 3u];
+        __syncthreads();
+    }
 
     // a launch with little (or no) work: wavefronts beyond one per 64 items leave before touching the work counter
     // (5120 same-address atomics cost ~40 us, which is most of an empty launch)
@@ -885,6 +916,17 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
                         r_out = idx;
                         r_sample = pp.y * fp.width + pp.x;   // frame pixel index, used for the id buffers
                         r_meta = 0u;
+                    } else if (io.shadow_compact != 0u && idx < n_shadow) {
+                        // compact shadow entry: the ray of mod.rs:149-153 from the shaded point, same operations as k_setup's
+                        const float4 a = io.shadow_q[idx];
+                        const uint32_t wd = __float_as_uint(a.w), l = wd >> COMPACT_SAMPLE_BITS;
+                        const F3 P = f3(a.x, a.y, a.z);
+                        const F3 ld = normalize(f3(s_light_pos[3u * l], s_light_pos[3u * l + 1u], s_light_pos[3u * l + 2u]) - P);   // mod.rs:149
+                        ro = P + scale(ld, fp.delta);                                                                            // mod.rs:151
+                        rd = ld;
+                        r_sample = wd & ((1u << COMPACT_SAMPLE_BITS) - 1u);
+                        r_meta = io.shadow_level | META_SHADOW | (l << 16);
+                        r_out = 0;
                     } else {
                         const float4* q = (idx < n_shadow) ? (io.shadow_q + (size_t)idx * 2u) : (io.chain_q + (size_t)(idx - n_shadow) * 2u);
                         float4 a = q[0], b = q[1];
@@ -1154,7 +1196,11 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
             base = __shfl(base, 0);
             n_sh += nh * L;
             uint32_t rank = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-            if (hit) {
+            if (hit && io.shadow_compact != 0u) {
+                // compact entries: the shaded point and (sample, light); the trace kernel rebuilds the ray
+                for (uint32_t l = 0; l < L; ++l)
+                    io.shadow_out[base + l * nh + rank] = make_float4(P.x, P.y, P.z, __uint_as_float(sample | (l << COMPACT_SAMPLE_BITS)));
+            } else if (hit) {
                 for (uint32_t l = 0; l < L; ++l) {
                     const LightRec* lt = fp.lights + l;
                     F3 ld = normalize(f3(lt->pos[0], lt->pos[1], lt->pos[2]) - P);   // mod.rs:149
@@ -1204,10 +1250,10 @@ DEV uint8_t quantize(float c) {   // render.rs:136-138: (c * 255.0) as u8
 // camera ray missed), a 48-byte record per shaded level (P, N, D, texture u v, material), the occluder code of every (level,
 // light) and -- where a reflective chain ends on an image sky (mod.rs:119, 125-127) -- the direction of that look-up in
 // `term`.  Levels are evaluated deepest first; the sample's colour goes to the `color` planes.
-__global__ void __launch_bounds__(256) k_resolve_samples(FrameParams fp, BatchParams bp, ResolveIO io) {
+DEV F3 resolve_sample(const FrameParams& fp, const BatchParams& bp, const ResolveIO& io, uint32_t s) {
     const uint32_t L = fp.n_lights;
     const size_t cap = bp.cap;
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < bp.n_samples; s += gridDim.x * blockDim.x) {
+    {
         const int n = io.nlev[s];
         F3 R = f3(fp.sky_color[0], fp.sky_color[1], fp.sky_color[2]);
         if (n == 0) {
@@ -1281,9 +1327,49 @@ __global__ void __launch_bounds__(256) k_resolve_samples(FrameParams fp, BatchPa
             }
             R = c;
         }
+        return R;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_resolve_samples(FrameParams fp, BatchParams bp, ResolveIO io) {
+    const size_t cap = bp.cap;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < bp.n_samples; s += gridDim.x * blockDim.x) {
+        const F3 R = resolve_sample(fp, bp, io, s);
         io.color[s] = R.x;
         io.color[cap + s] = R.y;
         io.color[2 * cap + s] = R.z;
+    }
+}
+
+// Both passes in one, for 1 or a power of two <= 64 samples per pixel (the reference's default is 16): one lane per SAMPLE
+// evaluates it, then the spp consecutive lanes of a pixel add their values in ascending sample order -- the order of the
+// sequential sum (mod.rs:248-249) -- and the first lane of the group writes the pixel.  The samples' colours never go to
+// memory (12 B written + 12 B read per sample saved, and a launch).  Whole wavefronts iterate together: the shuffles need
+// every lane present.
+__global__ void __launch_bounds__(256) k_resolve_fused(FrameParams fp, BatchParams bp, ResolveIO io) {
+    const uint32_t spp = fp.spp;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t base = lane & ~(spp - 1u);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (bp.n_samples + stride - 1) / stride;
+    for (uint32_t it = 0; it < rounds; ++it) {
+        const uint32_t s = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = s < bp.n_samples;   // n_samples is a multiple of spp: a group is valid or invalid as a whole
+        F3 v = f3(0.0f, 0.0f, 0.0f);
+        if (valid) v = resolve_sample(fp, bp, io, s);
+        F3 sum = f3(0.0f, 0.0f, 0.0f);
+        for (uint32_t j = 0; j < spp; ++j) {
+            F3 c = f3(__shfl(v.x, (int)(base + j)), __shfl(v.y, (int)(base + j)), __shfl(v.z, (int)(base + j)));
+            sum = sum + c;
+        }
+        if (valid && lane == base) {
+            const F3 color = fp.aa ? unscale(sum, (float)spp) : v;   // mod.rs:248-249 (spp > 1 implies aa)
+            const PixelPos pp = pixel_of(fp, bp, s / spp);
+            uint8_t* o = io.strip + (size_t)pp.strip_off * 3;
+            o[0] = quantize(color.x);
+            o[1] = quantize(color.y);
+            o[2] = quantize(color.z);
+        }
     }
 }
 
@@ -1485,10 +1571,20 @@ void launch_setup(bool level0, uint32_t grid, hipStream_t st, const FrameParams&
     else hipLaunchKernelGGL((k_setup<false>), g, b, 0, st, fp, bp, io, lvl);
 }
 
+// TRR_RESOLVE=two_pass keeps the two resolve kernels for every sample count (experiments, tests of that path)
+static bool resolve_two_pass() {
+    const char* e = std::getenv("TRR_RESOLVE");
+    return e && e[0] == 't';
+}
 void launch_resolve(uint32_t grid_samples, uint32_t grid_pixels, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
                     const ResolveIO& io) {
+    const bool pow2 = fp.spp >= 1u && fp.spp <= 64u && (fp.spp & (fp.spp - 1u)) == 0u;
+    if (pow2 && !resolve_two_pass()) {
+        hipLaunchKernelGGL(k_resolve_fused, dim3(grid_samples), dim3(256), 0, st, fp, bp, io);
+        return;
+    }
     hipLaunchKernelGGL(k_resolve_samples, dim3(grid_samples), dim3(256), 0, st, fp, bp, io);
-    const bool per_sample = fp.spp >= 2u && fp.spp <= 64u && (fp.spp & (fp.spp - 1u)) == 0u;   // k_resolve_pixels' coalesced form
+    const bool per_sample = pow2 && fp.spp >= 2u;   // k_resolve_pixels' coalesced form
     hipLaunchKernelGGL(k_resolve_pixels, dim3(per_sample ? grid_samples : grid_pixels), dim3(256), 0, st, fp, bp, io);
 }
 

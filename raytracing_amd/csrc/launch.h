@@ -21,6 +21,8 @@ struct TraceIO {
     const float4* src_q2;         // nullable: a second source queue, taken after src_q (levels-then-drain: shadow + chain queues)
     const uint32_t* src_n2;
     uint32_t src_cap2;
+    uint32_t src_compact;         // 1: src_q holds 16-B compact shadow entries of level src_level (kernels.hip: shadow entries)
+    uint32_t src_level;
     float4* spill_q;              // nullable: where a wavefront pushes once it can claim no more work items
     uint32_t* spill_n;
     uint32_t spill_cap;
@@ -32,8 +34,10 @@ struct TraceIO {
 };
 // the level-synchronous schedule's kernels
 struct LevelIO {
-    const float4* shadow_q;       // QUEUE: 32-B ray records of the level's shadow rays ...
-    const float4* chain_q;        // ... and of the next level's reflection rays
+    const float4* shadow_q;       // QUEUE: the level's shadow rays (32-B ray records, or 16-B compact entries) ...
+    const float4* chain_q;        // ... and the next level's reflection rays (32-B ray records)
+    uint32_t shadow_compact;      // 1: shadow_q holds compact entries, all of level shadow_level
+    uint32_t shadow_level;
     const uint32_t* n_shadow;
     const uint32_t* n_chain;
     uint32_t* work_counter;
@@ -54,6 +58,7 @@ struct SetupIO {
     uint8_t* nlev;
     float4* shadow_out;
     uint32_t* n_shadow_out;
+    uint32_t shadow_compact;      // 1: write 16-B compact shadow entries
     float4* chain_out;
     uint32_t* n_chain_out;
     unsigned long long* counters;
