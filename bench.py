@@ -181,7 +181,7 @@ def main():
             pass
         one_gpu = world == 1 and pmc is not None
         roofline = {
-            "bound": "valu", "kernel": "k_trace_level (camera-ray + secondary-ray launches)",
+            "bound": "valu", "kernel": "k_trace_level (camera-ray + secondary-ray launches) + k_trace (drain of the deep levels)",
             "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TFLOPS, 5),
             "traffic": int(pmc["hbm_bytes_per_frame"]) if one_gpu else None,
             "note": "fp32 vector work on an L2 / Infinity-Cache resident scene: no MFMA, HBM far from its peak (hbm_frac); achieved = "

@@ -22,6 +22,7 @@ cfgs = {
     "5": (lambda: standin.standin_mirrors(3840, 2160), 9, 1),
     "s8": (lambda: standin.standin_car(3840, 2160, anti_aliasing=True, samples=16), 5, 8),
     "s4": (lambda: standin.standin_car(3840, 2160, anti_aliasing=True, samples=16), 5, 4),
+    "s2": (lambda: standin.standin_car(3840, 2160, anti_aliasing=True, samples=16), 5, 2),
 }
 out = []
 for c in which:

@@ -20,6 +20,19 @@ def short(name):
     return name.replace("void trr::", "").replace("trr::", "").split("(")[0]
 
 
+def is_counter_build(k):
+    """k_trace<COUNT>, k_trace_level<RAYGEN, COUNT, QN>: the instantiations of the counter frame."""
+    if "<" not in k:
+        return False
+    name, args = k.split("<", 1)
+    a = [x.strip() for x in args.rstrip(">").split(",")]
+    if name == "k_trace":
+        return a[0] == "true"
+    if name == "k_trace_level":
+        return len(a) > 1 and a[1] == "true"
+    return False
+
+
 def main(root, frames, commit):
     tot = defaultdict(lambda: defaultdict(float))
     n = defaultdict(lambda: defaultdict(int))
@@ -29,7 +42,7 @@ def main(root, frames, commit):
             if c not in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"):
                 continue
             k = short(r["Kernel_Name"])
-            if not k.startswith("k_") or k.endswith(", true>") or k == "k_trace<true>":
+            if not k.startswith("k_") or is_counter_build(k):
                 continue
             tot[k][c] += float(r["Counter_Value"])
             n[k][c] += 1
