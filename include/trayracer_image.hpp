@@ -1,4 +1,4 @@
-// trayracer_image.hpp -- TIFF and baseline-JPEG decoding for the C++ scene loader (trayracer_loader.hpp), header-only C++17.
+// trayracer_image.hpp -- TIFF, baseline-JPEG and OpenEXR decoding for the C++ scene loader (trayracer_loader.hpp), header-only C++17.
 //
 // The reference opens every texture and sky image with `image::open(path)?.into_rgb8()` (src/scene/object.rs:31-38,
 // src/scene/skybox.rs:56-63): any format the `image` crate reads, reduced to 8-bit RGB.  Its own test scene uses TIFF
@@ -12,14 +12,21 @@
 //            (integer "islow" inverse DCT, "fancy" triangle-filter chroma upsampling, 16-bit fixed-point colour conversion), which
 //            is what Pillow (libjpeg-turbo) produces; the `image` crate's own decoder may differ by an LSB -- parity
 //            unpinned against the crate, within 1 LSB of Pillow by test.
-// Not decoded: tiled / 16-bit / float TIFF, progressive / arithmetic / 12-bit JPEG, OpenEXR (the reference's EXR skyboxes are
-// git-LFS stubs: there is nothing to pin a decoder against) -- loading such a file fails like a failed image::open.
+//   EXR   -- single-part scan-line / one-level tiled OpenEXR, HALF / FLOAT / UINT R G B, compression NONE, RLE, ZIPS, ZIP, PIZ,
+//            PXR24 (the reference's skyboxes are EXR).  Parity unpinned: the reference's own EXR files are git-LFS stubs,
+//            so the decoder is checked against files written by an independent encoder in tests/exr_writer.py only.
+// Not decoded: tiled / 16-bit / float TIFF, progressive / arithmetic / 12-bit JPEG, B44 / DWA / deep / multi-part EXR --
+// loading such a file fails like a failed image::open.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include <zlib.h>
 
 namespace trayracer {
 namespace imgdec {
@@ -577,6 +584,475 @@ inline Rgb8 decode(const std::string& d) {
     return im;
 }
 }   // namespace jpeg
+
+// ---------------------------------------------------------------------------------------------------------------
+// OpenEXR (the reference's skyboxes, res/skyboxes/*.exr; skybox.rs:56-63: image::open(path)?.into_rgb8()).
+// Single-part scan-line and one-level tiled files, HALF / FLOAT / UINT channels R, G, B (others ignored), compression NONE,
+// RLE, ZIPS, ZIP, PIZ, PXR24; restated from the published file-format documents ("OpenEXR File Layout", "Technical
+// Introduction") and the open-source library's PIZ description.  Reduced to 8 bits like the image crate's
+// Rgb32F -> Rgb8 conversion: round(clamp(v, 0, 1) * 255), linear, no tone mapping.
+// ---------------------------------------------------------------------------------------------------------------
+namespace exr {
+struct Cursor {
+    const uint8_t* p;
+    size_t n, o = 0;
+    void need(size_t k) const { if (o + k > n) throw DecodeError("truncated EXR"); }
+    uint8_t u8() { need(1); return p[o++]; }
+    uint32_t u32() { need(4); uint32_t v; std::memcpy(&v, p + o, 4); o += 4; return v; }
+    int32_t i32() { return (int32_t)u32(); }
+    uint64_t u64() { need(8); uint64_t v; std::memcpy(&v, p + o, 8); o += 8; return v; }
+    std::string cstr() {
+        std::string s;
+        for (;;) { need(1); char c = (char)p[o++]; if (!c) break; s.push_back(c); if (s.size() > 255) throw DecodeError("corrupt EXR header"); }
+        return s;
+    }
+};
+struct Channel {
+    std::string name;
+    int32_t type = 1;   // 0 UINT, 1 HALF, 2 FLOAT
+    int32_t xs = 1, ys = 1;
+    size_t bytes() const { return type == 1 ? 2 : 4; }
+};
+
+inline float half_to_float(uint16_t h) {
+    const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = s;
+        else {   // subnormal: renormalise
+            int sh = 0;
+            uint32_t mm = m;
+            while (!(mm & 1024u)) { mm <<= 1; ++sh; }
+            bits = s | ((uint32_t)(113 - sh) << 23) | ((mm & 1023u) << 13);
+        }
+    } else if (e == 31) bits = s | 0x7F800000u | (m << 13);
+    else bits = s | ((e + 112u) << 23) | (m << 13);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+// ---- RLE / ZIP: byte streams with a delta predictor and an even/odd split --------------------------------------------
+inline void unpredict_and_interleave(std::vector<uint8_t>& t, std::vector<uint8_t>& out) {
+    for (size_t i = 1; i < t.size(); ++i) t[i] = (uint8_t)(t[i - 1] + t[i] - 128);
+    out.resize(t.size());
+    const size_t half = (t.size() + 1) / 2;
+    for (size_t i = 0; i < t.size(); ++i) out[i] = (i & 1) ? t[half + i / 2] : t[i / 2];
+}
+inline void rle_decode(const uint8_t* src, size_t n, size_t want, std::vector<uint8_t>& out) {
+    out.clear();
+    size_t i = 0;
+    while (i < n) {
+        const int c = (int8_t)src[i++];
+        if (c < 0) {
+            const size_t k = (size_t)(-c);
+            if (i + k > n || out.size() + k > want) throw DecodeError("corrupt EXR RLE data");
+            out.insert(out.end(), src + i, src + i + k);
+            i += k;
+        } else {
+            if (i >= n || out.size() + (size_t)c + 1 > want) throw DecodeError("corrupt EXR RLE data");
+            out.insert(out.end(), (size_t)c + 1, src[i++]);
+        }
+    }
+    if (out.size() != want) throw DecodeError("short EXR RLE data");
+}
+inline void zlib_decode(const uint8_t* src, size_t n, size_t want, std::vector<uint8_t>& out) {
+    out.resize(want);
+    uLongf got = (uLongf)want;
+    if (::uncompress(out.data(), &got, src, (uLong)n) != Z_OK || got != want) throw DecodeError("corrupt EXR zlib data");
+}
+
+// ---- PIZ: value bitmap -> look-up table, Huffman-coded 16-bit symbols, 2-D Haar-like wavelet -----------------------
+namespace piz {
+constexpr int HUF_ENCBITS = 16, HUF_ENCSIZE = (1 << HUF_ENCBITS) + 1;
+constexpr int SHORT_ZEROCODE_RUN = 59, LONG_ZEROCODE_RUN = 63, SHORTEST_LONG_RUN = 2 + LONG_ZEROCODE_RUN - SHORT_ZEROCODE_RUN;
+struct Bits {
+    const uint8_t* p;
+    size_t n, o = 0;
+    uint64_t acc = 0;
+    int cnt = 0;
+    uint32_t get(int k) {   // most significant bit first
+        while (cnt < k) {
+            if (o >= n) throw DecodeError("truncated EXR PIZ data");
+            acc = (acc << 8) | p[o++];
+            cnt += 8;
+        }
+        cnt -= k;
+        return (uint32_t)((acc >> cnt) & ((1ull << k) - 1ull));
+    }
+};
+// code lengths of the symbols im..iM, 6 bits each, zero runs packed
+inline void unpack_lengths(const uint8_t* p, size_t n, uint32_t im, uint32_t iM, std::vector<uint8_t>& len, size_t* used) {
+    Bits b{p, n};
+    for (uint32_t i = im; i <= iM; ++i) {
+        const uint32_t l = b.get(6);
+        if (l == (uint32_t)LONG_ZEROCODE_RUN) {
+            uint32_t run = b.get(8) + SHORTEST_LONG_RUN;
+            if (i + run > iM + 1) throw DecodeError("corrupt EXR PIZ code table");
+            while (run--) len[i++] = 0;
+            --i;
+        } else if (l >= (uint32_t)SHORT_ZEROCODE_RUN) {
+            uint32_t run = l - SHORT_ZEROCODE_RUN + 2;
+            if (i + run > iM + 1) throw DecodeError("corrupt EXR PIZ code table");
+            while (run--) len[i++] = 0;
+            --i;
+        } else len[i] = (uint8_t)l;
+    }
+    *used = b.o;
+}
+inline void huf_uncompress(const uint8_t* src, size_t n, uint16_t* out, size_t n_out) {
+    if (n < 20) { if (n_out) throw DecodeError("truncated EXR PIZ data"); return; }
+    uint32_t im, iM, table_len, n_bits;
+    std::memcpy(&im, src, 4); std::memcpy(&iM, src + 4, 4); std::memcpy(&table_len, src + 8, 4); std::memcpy(&n_bits, src + 12, 4);
+    if ((size_t)table_len > n - 20) throw DecodeError("corrupt EXR PIZ header");
+    if (im >= (uint32_t)HUF_ENCSIZE || iM >= (uint32_t)HUF_ENCSIZE || im > iM) throw DecodeError("corrupt EXR PIZ header");
+    std::vector<uint8_t> len(HUF_ENCSIZE, 0);
+    size_t used = 0;
+    unpack_lengths(src + 20, table_len, im, iM, len, &used);
+    used = table_len;
+    // canonical codes: lengths 58 .. 1, the longest codes numerically first (start[l]); inside a length by symbol
+    uint64_t count[59] = {0}, start[59] = {0};
+    for (uint32_t i = im; i <= iM; ++i) count[len[i]]++;
+    uint64_t c = 0;
+    for (int l = 58; l > 0; --l) { const uint64_t nc = (c + count[l]) >> 1; start[l] = c; c = nc; }
+    std::vector<uint32_t> first(60, 0), syms;
+    syms.reserve(iM - im + 1);
+    for (int l = 1; l <= 58; ++l) {
+        first[l] = (uint32_t)syms.size();
+        if (count[l]) for (uint32_t i = im; i <= iM; ++i) if (len[i] == l) syms.push_back(i);
+    }
+    // a 12-bit table for the short codes, bit-by-bit beyond
+    constexpr int FAST = 12;
+    std::vector<uint32_t> fast(1u << FAST, 0);   // (symbol << 6) | length, 0 = longer code
+    for (int l = 1; l <= FAST; ++l)
+        for (uint64_t k = 0; k < count[l]; ++k) {
+            const uint64_t code = start[l] + k;
+            const uint32_t s = syms[first[l] + (uint32_t)k];
+            const uint32_t base = (uint32_t)(code << (FAST - l));
+            for (uint32_t f = 0; f < (1u << (FAST - l)); ++f) fast[base + f] = (s << 6) | (uint32_t)l;
+        }
+    const uint8_t* data = src + 20 + used;
+    const size_t data_n = n - 20 - used;
+    if ((size_t)(n_bits + 7) / 8 > data_n) throw DecodeError("truncated EXR PIZ data");
+    const uint32_t rlc = iM;
+    size_t bit = 0, o = 0;
+    auto peek = [&](size_t at, int k) -> uint32_t {   // k <= 32 bits at bit offset `at`, zero-padded past the end
+        uint64_t v = 0;
+        const size_t byte = at >> 3;
+        for (int j = 0; j < 6; ++j) v = (v << 8) | (byte + j < data_n ? data[byte + j] : 0);
+        return (uint32_t)((v >> (48 - (at & 7) - k)) & ((1ull << k) - 1ull));
+    };
+    while (bit < n_bits) {
+        uint32_t sym;
+        const uint32_t f = fast[peek(bit, FAST)];
+        if (f) { sym = f >> 6; bit += f & 63u; }
+        else {
+            uint64_t code = peek(bit, FAST);
+            int l = FAST;
+            bool found = false;
+            while (l < 58) {
+                ++l;
+                code = (code << 1) | peek(bit + l - 1, 1);
+                if (count[l] && code >= start[l] && code - start[l] < count[l]) { sym = syms[first[l] + (uint32_t)(code - start[l])]; found = true; break; }
+            }
+            if (!found) throw DecodeError("corrupt EXR PIZ code");
+            bit += (size_t)l;
+        }
+        if (bit > n_bits) throw DecodeError("corrupt EXR PIZ data");
+        if (sym == rlc) {
+            if (bit + 8 > n_bits || o == 0) throw DecodeError("corrupt EXR PIZ run");
+            const uint32_t run = peek(bit, 8);
+            bit += 8;
+            if (o + run > n_out) throw DecodeError("corrupt EXR PIZ run");
+            const uint16_t v = out[o - 1];
+            for (uint32_t k = 0; k < run; ++k) out[o++] = v;
+        } else {
+            if (o >= n_out) throw DecodeError("corrupt EXR PIZ data (too many symbols)");
+            out[o++] = (uint16_t)sym;
+        }
+    }
+    if (o != n_out) throw DecodeError("short EXR PIZ data");
+}
+inline void wdec14(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+    const int16_t ls = (int16_t)l, hs = (int16_t)h;
+    const int hi = hs, ai = ls + (hi & 1) + (hi >> 1);
+    a = (uint16_t)(int16_t)ai;
+    b = (uint16_t)(int16_t)(ai - hi);
+}
+inline void wdec16(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+    const int m = l, d = h;
+    const int bb = (m - (d >> 1)) & 0xFFFF, aa = (d + bb - 0x8000) & 0xFFFF;
+    b = (uint16_t)bb;
+    a = (uint16_t)aa;
+}
+inline void wav2_decode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t mx) {
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx;
+    int p = 1, p2;
+    while (p <= n) p <<= 1;
+    p >>= 1;
+    p2 = p;
+    p >>= 1;
+    auto dec = [&](uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) { if (w14) wdec14(l, h, a, b); else wdec16(l, h, a, b); };
+    while (p >= 1) {
+        uint16_t* py = in;
+        uint16_t* const ey = in + (ptrdiff_t)oy * (ny - p2);
+        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            uint16_t* px = py;
+            uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t* p01 = px + ox1;
+                uint16_t* p10 = px + oy1;
+                uint16_t* p11 = p10 + ox1;
+                dec(*px, *p10, i00, i10);
+                dec(*p01, *p11, i01, i11);
+                dec(i00, i01, *px, *p01);
+                dec(i10, i11, *p10, *p11);
+            }
+            if (nx & p) {
+                uint16_t* p10 = px + oy1;
+                dec(*px, *p10, i00, *p10);
+                *px = i00;
+            }
+        }
+        if (ny & p) {
+            uint16_t* px = py;
+            uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t* p01 = px + ox1;
+                dec(*px, *p01, i00, *p01);
+                *px = i00;
+            }
+        }
+        p2 = p;
+        p >>= 1;
+    }
+}
+// one block: `ny` lines of `nx` pixels, channels in file order; the result has the uncompressed block's layout
+inline void decode_block(const uint8_t* src, size_t n, const std::vector<Channel>& ch, int nx, int ny, std::vector<uint8_t>& out) {
+    size_t words = 0;
+    for (const Channel& c : ch) words += (size_t)nx * ny * (c.bytes() / 2);
+    std::vector<uint16_t> tmp(words);
+    if (n < 4) throw DecodeError("truncated EXR PIZ block");
+    uint16_t min_nz, max_nz;
+    std::memcpy(&min_nz, src, 2); std::memcpy(&max_nz, src + 2, 2);
+    size_t o = 4;
+    std::vector<uint8_t> bitmap(8192, 0);
+    if (max_nz >= 8192) throw DecodeError("corrupt EXR PIZ bitmap");
+    if (min_nz <= max_nz) {
+        const size_t k = (size_t)max_nz - min_nz + 1;
+        if (o + k > n) throw DecodeError("truncated EXR PIZ bitmap");
+        std::memcpy(bitmap.data() + min_nz, src + o, k);
+        o += k;
+    }
+    std::vector<uint16_t> lut(65536, 0);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < 65536; ++i)
+        if (i == 0 || (bitmap[i >> 3] & (1u << (i & 7)))) lut[k++] = (uint16_t)i;
+    const uint16_t max_value = (uint16_t)(k - 1);
+    if (o + 4 > n) throw DecodeError("truncated EXR PIZ block");
+    int32_t length;
+    std::memcpy(&length, src + o, 4);
+    o += 4;
+    if (length < 0 || o + (size_t)length > n) throw DecodeError("corrupt EXR PIZ block length");
+    huf_uncompress(src + o, (size_t)length, tmp.data(), words);
+    std::vector<uint16_t*> start(ch.size());
+    uint16_t* q = tmp.data();
+    for (size_t c = 0; c < ch.size(); ++c) {
+        start[c] = q;
+        const int size = (int)(ch[c].bytes() / 2);
+        for (int j = 0; j < size; ++j) wav2_decode(q + j, nx, size, ny, nx * size, max_value);
+        q += (size_t)nx * ny * size;
+    }
+    for (uint16_t& v : tmp) v = lut[v];
+    out.resize(words * 2);
+    uint8_t* w = out.data();
+    for (int y = 0; y < ny; ++y)
+        for (size_t c = 0; c < ch.size(); ++c) {
+            const size_t cnt = (size_t)nx * (ch[c].bytes() / 2);
+            std::memcpy(w, start[c], cnt * 2);
+            start[c] += cnt;
+            w += cnt * 2;
+        }
+}
+}   // namespace piz
+
+// PXR24: zlib, then per line and channel byte planes (most significant first) of running sums; FLOAT keeps 24 bits
+inline void pxr24_decode(const uint8_t* src, size_t n, const std::vector<Channel>& ch, int nx, int ny, std::vector<uint8_t>& out) {
+    size_t packed = 0, full = 0;
+    for (const Channel& c : ch) { packed += (size_t)nx * ny * (c.type == 2 ? 3 : c.bytes()); full += (size_t)nx * ny * c.bytes(); }
+    std::vector<uint8_t> t(packed);
+    uLongf got = (uLongf)packed;
+    if (::uncompress(t.data(), &got, src, (uLong)n) != Z_OK || got != packed) throw DecodeError("corrupt EXR PXR24 data");
+    out.resize(full);
+    const uint8_t* p = t.data();
+    uint8_t* w = out.data();
+    for (int y = 0; y < ny; ++y)
+        for (const Channel& c : ch) {
+            if (c.type == 1) {
+                const uint8_t *p0 = p, *p1 = p + nx;
+                p += 2 * (size_t)nx;
+                uint32_t px = 0;
+                for (int x = 0; x < nx; ++x) { px += ((uint32_t)p0[x] << 8) | p1[x]; const uint16_t v = (uint16_t)px; std::memcpy(w, &v, 2); w += 2; }
+            } else if (c.type == 2) {
+                const uint8_t *p0 = p, *p1 = p + nx, *p2 = p + 2 * (size_t)nx;
+                p += 3 * (size_t)nx;
+                uint32_t px = 0;
+                for (int x = 0; x < nx; ++x) { px += ((uint32_t)p0[x] << 24) | ((uint32_t)p1[x] << 16) | ((uint32_t)p2[x] << 8); std::memcpy(w, &px, 4); w += 4; }
+            } else {
+                const uint8_t *p0 = p, *p1 = p + nx, *p2 = p + 2 * (size_t)nx, *p3 = p + 3 * (size_t)nx;
+                p += 4 * (size_t)nx;
+                uint32_t px = 0;
+                for (int x = 0; x < nx; ++x) { px += ((uint32_t)p0[x] << 24) | ((uint32_t)p1[x] << 16) | ((uint32_t)p2[x] << 8) | p3[x]; std::memcpy(w, &px, 4); w += 4; }
+            }
+        }
+}
+
+inline uint8_t to_u8(float v) {   // image crate: (v.clamp(0, 1) * 255).round() as u8
+    if (!(v == v)) return 0;
+    const float c = v < 0.0f ? 0.0f : v > 1.0f ? 1.0f : v;
+    return (uint8_t)std::lround(c * 255.0f);
+}
+
+inline Rgb8 decode(const std::string& d) {
+    Cursor r{reinterpret_cast<const uint8_t*>(d.data()), d.size()};
+    if (r.u32() != 20000630u) throw DecodeError("not an OpenEXR file");
+    const uint32_t version = r.u32();
+    if ((version & 0xFFu) != 2u) throw DecodeError("unsupported OpenEXR version");
+    if (version & 0x1800u) throw DecodeError("unsupported OpenEXR file (deep or multi-part)");
+    const bool tiled = (version & 0x200u) != 0;
+    std::vector<Channel> ch;
+    int compression = -1, line_order = 0;
+    int32_t dw[4] = {0, 0, -1, -1};
+    uint32_t tile_w = 0, tile_h = 0, tile_mode = 0;
+    bool have_dw = false;
+    for (;;) {
+        const std::string name = r.cstr();
+        if (name.empty()) break;
+        const std::string type = r.cstr();
+        const int32_t size = r.i32();
+        if (size < 0) throw DecodeError("corrupt EXR header");
+        r.need((size_t)size);
+        Cursor a{r.p + r.o, (size_t)size};
+        r.o += (size_t)size;
+        if (name == "channels" && type == "chlist") {
+            for (;;) {
+                Channel c;
+                c.name = a.cstr();
+                if (c.name.empty()) break;
+                c.type = a.i32();
+                a.u32();   // pLinear + reserved
+                c.xs = a.i32();
+                c.ys = a.i32();
+                if (c.type < 0 || c.type > 2) throw DecodeError("corrupt EXR channel type");
+                ch.push_back(c);
+            }
+        } else if (name == "compression") compression = a.u8();
+        else if (name == "dataWindow" && type == "box2i") { for (int k = 0; k < 4; ++k) dw[k] = a.i32(); have_dw = true; }
+        else if (name == "lineOrder") line_order = a.u8();
+        else if (name == "tiles" && type == "tiledesc") { tile_w = a.u32(); tile_h = a.u32(); tile_mode = a.u8(); }
+    }
+    (void)line_order;   // blocks are found through the offset table and carry their own y
+    if (ch.empty() || !have_dw || compression < 0) throw DecodeError("EXR header lacks channels, dataWindow or compression");
+    const int64_t W = (int64_t)dw[2] - dw[0] + 1, H = (int64_t)dw[3] - dw[1] + 1;
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) throw DecodeError("unsupported EXR size");
+    int idx[3] = {-1, -1, -1};
+    for (size_t c = 0; c < ch.size(); ++c) {
+        if (ch[c].xs != 1 || ch[c].ys != 1) throw DecodeError("unsupported EXR (sub-sampled channels)");
+        if (ch[c].name == "R") idx[0] = (int)c;
+        else if (ch[c].name == "G") idx[1] = (int)c;
+        else if (ch[c].name == "B") idx[2] = (int)c;
+    }
+    if (idx[0] < 0 || idx[1] < 0 || idx[2] < 0) throw DecodeError("EXR without R, G and B channels");
+    int lines_per_block;
+    switch (compression) {
+        case 0: case 1: case 2: lines_per_block = 1; break;
+        case 3: case 5: lines_per_block = 16; break;
+        case 4: lines_per_block = 32; break;
+        default: throw DecodeError("unsupported EXR compression " + std::to_string(compression) + " (B44 / DWA)");
+    }
+    size_t px_bytes = 0;   // bytes of one pixel over all channels
+    std::vector<size_t> ch_off(ch.size());
+    for (size_t c = 0; c < ch.size(); ++c) px_bytes += ch[c].bytes();
+    Rgb8 im;
+    im.width = (uint32_t)W; im.height = (uint32_t)H;
+    im.rgb.assign((size_t)W * H * 3, 0);
+    std::vector<uint8_t> raw, tmp;
+    // decodes one block of nx x ny pixels whose top-left pixel is (x0, y0) in image coordinates
+    auto block = [&](const uint8_t* src, size_t n, int x0, int y0, int nx, int ny) {
+        const size_t want = px_bytes * (size_t)nx * ny;
+        const uint8_t* data = src;
+        if (n == want || compression == 0) {   // stored raw when compression did not help
+            if (n < want) throw DecodeError("short EXR block");
+        } else {
+            if (compression == 1) { rle_decode(src, n, want, tmp); unpredict_and_interleave(tmp, raw); }
+            else if (compression == 2 || compression == 3) { zlib_decode(src, n, want, tmp); unpredict_and_interleave(tmp, raw); }
+            else if (compression == 4) piz::decode_block(src, n, ch, nx, ny, raw);
+            else pxr24_decode(src, n, ch, nx, ny, raw);
+            if (raw.size() != want) throw DecodeError("corrupt EXR block");
+            data = raw.data();
+        }
+        for (int y = 0; y < ny; ++y) {
+            const uint8_t* line = data + px_bytes * (size_t)nx * y;
+            size_t off = 0;
+            for (size_t c = 0; c < ch.size(); ++c) {
+                const size_t bytes = ch[c].bytes();
+                int comp = -1;
+                for (int k = 0; k < 3; ++k) if (idx[k] == (int)c) comp = k;
+                if (comp >= 0) {
+                    uint8_t* o = im.rgb.data() + ((size_t)(y0 + y) * W + x0) * 3 + comp;
+                    const uint8_t* s = line + off;
+                    for (int x = 0; x < nx; ++x, o += 3, s += bytes) {
+                        float v;
+                        if (ch[c].type == 1) { uint16_t h; std::memcpy(&h, s, 2); v = half_to_float(h); }
+                        else if (ch[c].type == 2) std::memcpy(&v, s, 4);
+                        else { uint32_t u; std::memcpy(&u, s, 4); v = (float)u; }
+                        *o = to_u8(v);
+                    }
+                }
+                off += bytes * (size_t)nx;
+            }
+        }
+    };
+    if (!tiled) {
+        const size_t n_blocks = (size_t)((H + lines_per_block - 1) / lines_per_block);
+        std::vector<uint64_t> offs(n_blocks);
+        for (uint64_t& o : offs) o = r.u64();
+        for (uint64_t o : offs) {
+            Cursor b{r.p, r.n, (size_t)o};
+            if (o > r.n) throw DecodeError("corrupt EXR offset table");
+            const int32_t y = b.i32();
+            const int32_t size = b.i32();
+            if (size < 0) throw DecodeError("corrupt EXR block");
+            b.need((size_t)size);
+            const int64_t y0 = (int64_t)y - dw[1];
+            if (y0 < 0 || y0 >= H) throw DecodeError("corrupt EXR block position");
+            const int ny = (int)std::min<int64_t>(lines_per_block, H - y0);
+            block(b.p + b.o, (size_t)size, 0, (int)y0, (int)W, ny);
+        }
+    } else {
+        if (tile_w == 0 || tile_h == 0 || tile_w > 65535 || tile_h > 65535) throw DecodeError("corrupt EXR tile description");
+        (void)tile_mode;   // mip / rip maps: level (0, 0) comes first in the offset table and is all that is read
+        const size_t tx = (size_t)((W + tile_w - 1) / tile_w), ty = (size_t)((H + tile_h - 1) / tile_h);
+        std::vector<uint64_t> offs(tx * ty);
+        for (uint64_t& o : offs) o = r.u64();
+        for (uint64_t o : offs) {
+            if (o > r.n) throw DecodeError("corrupt EXR offset table");
+            Cursor b{r.p, r.n, (size_t)o};
+            const int32_t txi = b.i32(), tyi = b.i32(), lx = b.i32(), ly = b.i32();
+            const int32_t size = b.i32();
+            if (size < 0 || lx != 0 || ly != 0 || txi < 0 || tyi < 0 || (size_t)txi >= tx || (size_t)tyi >= ty) throw DecodeError("corrupt EXR tile");
+            b.need((size_t)size);
+            const int x0 = (int)(txi * (int64_t)tile_w), y0 = (int)(tyi * (int64_t)tile_h);
+            const int nx = (int)std::min<int64_t>(tile_w, W - x0), ny = (int)std::min<int64_t>(tile_h, H - y0);
+            block(b.p + b.o, (size_t)size, x0, y0, nx, ny);
+        }
+    }
+    return im;
+}
+}   // namespace exr
 
 }   // namespace imgdec
 }   // namespace trayracer

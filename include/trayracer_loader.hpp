@@ -176,8 +176,9 @@ inline Image load_image_rgb8(const std::string& path) {
         if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') return decode_ppm(d);
         const bool is_tiff = d.size() >= 4 && ((d[0] == 'I' && d[1] == 'I' && d[2] == 42 && d[3] == 0) || (d[0] == 'M' && d[1] == 'M' && d[2] == 0 && d[3] == 42));
         const bool is_jpeg = d.size() >= 3 && (unsigned char)d[0] == 0xFF && (unsigned char)d[1] == 0xD8;
-        if (is_tiff || is_jpeg) {
-            imgdec::Rgb8 r = is_tiff ? imgdec::tiff::decode(d) : imgdec::jpeg::decode(d);
+        const bool is_exr = d.size() >= 4 && (unsigned char)d[0] == 0x76 && (unsigned char)d[1] == 0x2F && (unsigned char)d[2] == 0x31 && (unsigned char)d[3] == 0x01;
+        if (is_tiff || is_jpeg || is_exr) {
+            imgdec::Rgb8 r = is_tiff ? imgdec::tiff::decode(d) : is_jpeg ? imgdec::jpeg::decode(d) : imgdec::exr::decode(d);
             Image im;
             im.width = r.width; im.height = r.height;
             im.rgb = std::move(r.rgb);

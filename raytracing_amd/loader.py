@@ -253,6 +253,13 @@ def parse_mtl(text: str) -> List[MtlMaterial]:
 def load_image_rgb8(path: str) -> np.ndarray:
     """``image::open(path)?.into_rgb8()`` -> uint8 [h, w, 3] (object.rs:31-38, skybox.rs:57-64)."""
     try:
+        with open(path, "rb") as f:
+            magic = f.read(4)
+    except OSError as e:
+        raise SceneLoadError(f"Failed to load image from path: {path}: {e}") from None
+    if magic == b"\x76\x2f\x31\x01":
+        return _load_exr_rgb8(path)
+    try:
         from PIL import Image
     except ImportError as e:   # pragma: no cover - Pillow is present in the build image
         raise SceneLoadError(f"cannot decode {path}: Pillow is not importable") from e
@@ -261,6 +268,28 @@ def load_image_rgb8(path: str) -> np.ndarray:
             return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
     except Exception as e:   # noqa: BLE001 - any decoder failure is one load failure
         raise SceneLoadError(f"Failed to load image from path: {path}: {e}") from None
+
+
+def _load_exr_rgb8(path: str) -> np.ndarray:
+    """OpenEXR (the reference's skyboxes): Pillow does not read it, so the C++ loader's decoder does the work
+    (include/trayracer_image.hpp, through `examples/trr_cli --decode-image`, which touches no GPU)."""
+    import subprocess
+    import tempfile
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "trr_cli")
+    if not os.path.exists(cli):
+        raise SceneLoadError(f"Failed to load image from path: {path}: EXR needs examples/trr_cli (make -C raytracing_amd/csrc)")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "image.ppm")
+        r = subprocess.run([cli, "--decode-image", path, out], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise SceneLoadError(f"Failed to load image from path: {path}: {(r.stderr or r.stdout).strip()}")
+        with open(out, "rb") as f:
+            d = f.read()
+    head = d.split(b"\n", 3)   # "P6", "w h", "255", pixels
+    if len(head) != 4 or head[0] != b"P6":
+        raise SceneLoadError(f"Failed to load image from path: {path}: unexpected decoder output")
+    w, h = (int(x) for x in head[1].split())
+    return np.frombuffer(head[3], np.uint8, w * h * 3).reshape(h, w, 3).copy()
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -208,3 +208,22 @@ def test_tiff_and_jpeg_textures_load_the_same_in_both_loaders(tmp_path):
     assert np.array_equal(want.objects[0].materials[0].diffuse_texture, tex)
     assert want.objects[0].materials[1].diffuse_texture.shape == (33, 50, 3)
     same_scene(want, got)
+
+
+def test_an_exr_skybox_loads_the_same_in_both_loaders(tmp_path):
+    """skybox.rs:56-63: the reference's skyboxes are OpenEXR.  Both loaders reduce the file to the same RGB8 image (one
+    decoder: include/trayracer_image.hpp; the file comes from the tests' own encoder, tests/exr_writer.py)."""
+    from tests import exr_writer as W
+    h, w = 32, 64
+    y_, x_ = np.mgrid[0:h, 0:w].astype(np.float32)
+    sky = {"R": (W.HALF, x_ / w * 1.5), "G": (W.HALF, y_ / h), "B": (W.HALF, np.full((h, w), 4.0, np.float32))}
+    sky_path = os.path.join(str(tmp_path), "sky.exr")   # (the reference opens the path as given, relative to the process)
+    W.write_exr(sky_path, sky, W.PIZ)
+    T._write(tmp_path, "quad.mtl", T.QUAD_MTL)
+    T._write(tmp_path, "quad.obj", T.QUAD_OBJ)
+    y = T._write(tmp_path, "c.yaml", T._yaml_with(T.EXTRA.replace("!Color [0.1, 0.2, 0.3]", "!Path " + sky_path)))
+    got, _ = cpp_load(y, tmp_path)
+    want = loader.load_scene(y)
+    img = want.settings.skybox.image
+    assert img.shape == (h, w, 3) and img[0, -1, 0] == 255 and img[5, 5, 2] == 255 and img[16, 0, 1] == 128
+    same_scene(want, got)
