@@ -1,6 +1,7 @@
 // trace_step.inl -- ONE traversal step of a wavefront, included textually in the loop of both trace kernels (k_trace and
 // k_trace_level in kernels.hip), which declare the state it works on: cur, sp, fl, oo, od, oi, lim_n, slack_abs, o_key,
-// o_slot, o_tri (per lane), tid, lane, s_stack, push / pop, g_nodes, g_tris, delta, the c_* counters and the F_* flag bits.
+// o_slot, o_tri, e_ray (per lane), tid, lane, s_stack, push / pop, g_nodes, g_qnodes, g_tris, delta, QN (which node format),
+// the c_* counters and the F_* flag bits.
         // ---- one step per iteration, chosen for the WHOLE wavefront: either every lane that stands on an inner node
         // visits it, or every lane that stands on a leaf tests ONE of its triangles.  The kind with more waiting lanes
         // runs (node steps weighted by NODE_BIAS/8); the other lanes keep their state for a later iteration.  A step
@@ -62,57 +63,57 @@
 #undef TRR_QBOX
                 } else {
 #ifdef TRR_UNIFORM_SCALAR
-                // experiment (kept out): when every lane of the step stands on the SAME node, fetch it once
-                // through the scalar cache instead of 64 x 112 B through the vector memory path
-                float4 lox, loy, loz, hix, hiy, hiz;
-                uint4 ch;
-                {
-                    const uint32_t cur_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-                    if (__ballot(cur == cur_first) == __ballot(true)) {
-                        typedef const float __attribute__((address_space(4))) * cfp;
-                        typedef const uint32_t __attribute__((address_space(4))) * cup;
-                        cfp sf = (cfp)(uintptr_t)(g_nodes + cur_first);
-                        cup su = (cup)(uintptr_t)(g_nodes + cur_first);
-                        lox = make_float4(sf[0], sf[1], sf[2], sf[3]); loy = make_float4(sf[4], sf[5], sf[6], sf[7]);
-                        loz = make_float4(sf[8], sf[9], sf[10], sf[11]); hix = make_float4(sf[12], sf[13], sf[14], sf[15]);
-                        hiy = make_float4(sf[16], sf[17], sf[18], sf[19]); hiz = make_float4(sf[20], sf[21], sf[22], sf[23]);
-                        ch = make_uint4(su[24], su[25], su[26], su[27]);
-                    } else {
-                        const float4* nd = reinterpret_cast<const float4*>(g_nodes + cur);
-                        lox = nd[0]; loy = nd[1]; loz = nd[2]; hix = nd[3]; hiy = nd[4]; hiz = nd[5];
-                        ch = *reinterpret_cast<const uint4*>(nd + 6);
+                    // experiment (kept out): when every lane of the step stands on the SAME node, fetch it once
+                    // through the scalar cache instead of 64 x 112 B through the vector memory path
+                    float4 lox, loy, loz, hix, hiy, hiz;
+                    uint4 ch;
+                    {
+                        const uint32_t cur_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                        if (__ballot(cur == cur_first) == __ballot(true)) {
+                            typedef const float __attribute__((address_space(4))) * cfp;
+                            typedef const uint32_t __attribute__((address_space(4))) * cup;
+                            cfp sf = (cfp)(uintptr_t)(g_nodes + cur_first);
+                            cup su = (cup)(uintptr_t)(g_nodes + cur_first);
+                            lox = make_float4(sf[0], sf[1], sf[2], sf[3]); loy = make_float4(sf[4], sf[5], sf[6], sf[7]);
+                            loz = make_float4(sf[8], sf[9], sf[10], sf[11]); hix = make_float4(sf[12], sf[13], sf[14], sf[15]);
+                            hiy = make_float4(sf[16], sf[17], sf[18], sf[19]); hiz = make_float4(sf[20], sf[21], sf[22], sf[23]);
+                            ch = make_uint4(su[24], su[25], su[26], su[27]);
+                        } else {
+                            const float4* nd = reinterpret_cast<const float4*>(g_nodes + cur);
+                            lox = nd[0]; loy = nd[1]; loz = nd[2]; hix = nd[3]; hiy = nd[4]; hiz = nd[5];
+                            ch = *reinterpret_cast<const uint4*>(nd + 6);
+                        }
                     }
-                }
 #else
-                const float4* nd = reinterpret_cast<const float4*>(g_nodes + cur);
-                float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
-                uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
+                    const float4* nd = reinterpret_cast<const float4*>(g_nodes + cur);
+                    float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
+                    uint4 ch = *reinterpret_cast<const uint4*>(nd + 6);
 #endif
 #ifdef TRR_DUMMY_LOAD
-                {   // experiment: TRR_DUMMY_LOAD more 16-B loads per lane from the node's own cache line, through a pointer the
-                    // optimiser cannot see through (is the vector memory path a limit, and how steep is it?)
-                    const float4* xp = reinterpret_cast<const float4*>(g_nodes + cur);
-                    asm volatile("" : "+v"(xp));
+                    {   // experiment: TRR_DUMMY_LOAD more 16-B loads per lane from the node's own cache line, through a pointer the
+                        // optimiser cannot see through (is the vector memory path a limit, and how steep is it?)
+                        const float4* xp = reinterpret_cast<const float4*>(g_nodes + cur);
+                        asm volatile("" : "+v"(xp));
 #pragma unroll
-                    for (int k = 0; k < TRR_DUMMY_LOAD; ++k) {
-                        float4 extra = xp[(7 + k) & 7];
-                        asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
+                        for (int k = 0; k < TRR_DUMMY_LOAD; ++k) {
+                            float4 extra = xp[(7 + k) & 7];
+                            asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
+                        }
                     }
-                }
 #endif
 #ifdef TRR_DUMMY_VALU
-                {   // experiment: TRR_DUMMY_VALU extra dependent vector instructions per node step (is the kernel VALU-bound?)
-                    float dv = lox.x;
+                    {   // experiment: TRR_DUMMY_VALU extra dependent vector instructions per node step (is the kernel VALU-bound?)
+                        float dv = lox.x;
 #pragma unroll
-                    for (int k = 0; k < TRR_DUMMY_VALU; ++k) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dv));
-                    asm volatile("" ::"v"(dv));
-                }
+                        for (int k = 0; k < TRR_DUMMY_VALU; ++k) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dv));
+                        asm volatile("" ::"v"(dv));
+                    }
 #endif
-                // [crate] Ray::intersects_aabb per child, same arithmetic as the per-triangle test below, so a parent
-                // box (exact union of its children) can never reject what a triangle's own box accepts.  Written with
-                // scalars and selects only (no arrays, no short-circuit branches): keeps the step branch-free.
-                // An unused child slot holds the box (+inf .. +inf), which fails the test for every ray; a NaN tmin keeps
-                // the child (NaN > x is false) and simply does not take part in the ordering.
+                    // [crate] Ray::intersects_aabb per child, same arithmetic as the per-triangle test below, so a parent
+                    // box (exact union of its children) can never reject what a triangle's own box accepts.  Written with
+                    // scalars and selects only (no arrays, no short-circuit branches): keeps the step branch-free.
+                    // An unused child slot holds the box (+inf .. +inf), which fails the test for every ray; a NaN tmin keeps
+                    // the child (NaN > x is false) and simply does not take part in the ordering.
 #define TRR_BOX(T, R, LX, LY, LZ, HX, HY, HZ, CH)                                                          \
     {                                                                                                      \
         float ax = ((LX) - oo.x) * oi.x, bx = ((HX) - oo.x) * oi.x;                                        \
@@ -124,10 +125,10 @@
         T = hit ? tmin : INFINITY;                                                                         \
         R = hit ? (CH) : REF_EMPTY;                                                                        \
     }
-                TRR_BOX(t0, r0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x)
-                TRR_BOX(t1, r1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y)
-                TRR_BOX(t2, r2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
-                TRR_BOX(t3, r3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
+                    TRR_BOX(t0, r0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x)
+                    TRR_BOX(t1, r1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y)
+                    TRR_BOX(t2, r2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
+                    TRR_BOX(t3, r3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
 #undef TRR_BOX
                 }
                 // sort the four (tmin, ref) pairs ascending: 5-comparator network of selects
