@@ -325,8 +325,9 @@ def test_sharded_renderer_pipelined_frames_are_identical(ctx):
             assert np.array_equal(f.cpu().numpy(), want), f"frame {k} of the pipelined sequence differs"
         for st in stats:
             assert st.rays() == sync_stats.rays() and st.rays_shadow == sync_stats.rays_shadow
-            # one batch per pipelined frame (TRR_FLAG_PIPELINED) against two for the lone frame: one trace launch per batch
-            assert st.trace_launches * 2 == sync_stats.trace_launches and st.blocks_rendered == 400
+            # one batch per pipelined frame (TRR_FLAG_PIPELINED) against four for the lone small frame: one (persistent) trace
+            # launch per batch
+            assert st.trace_launches * 4 == sync_stats.trace_launches and st.blocks_rendered == 400
             assert st.queue_overflows == 0
             assert st.ms_trace > 0 and st.ms_total > 0
     finally:
