@@ -1321,7 +1321,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     // tails behind the other frame and only pays k_trace's dearer rays (30.6 / 31.3, 12.3 / 13.4), so it keeps the levels.
     grids.drain_level = (flags & TRR_FLAG_PIPELINED) ? NO_DRAIN : 2u;
     if (const char* e = std::getenv("TRR_DRAIN_LEVEL")) grids.drain_level = std::atoi(e) < 0 ? NO_DRAIN : (uint32_t)std::atoi(e);
-    const bool drains = schedule == SCHED_LEVELS && grids.drain_level + 1 < max_depth;
+    const bool drains = schedule == SCHED_LEVELS && grids.drain_level != NO_DRAIN && grids.drain_level + 1 < max_depth;
     const uint32_t trace_grid = schedule == SCHED_PERSISTENT ? grids.trace
                                                              : std::max(std::max(grids.raygen, grids.secondary), drains ? grids.trace : 0u);   // sizes the stack-spill area
     if (std::getenv("TRR_DEBUG"))
