@@ -4,7 +4,7 @@
 //   Scene::load (include/trayracer_loader.hpp) -> Raytracer(scene, 1e-5, 5) (render.rs:105) -> RGB8 frame -> file.
 //
 //   usage: trr_cli <scene.yaml> [-o out.png|out.ppm] [--width W] [--height H] [--max-depth D] [--delta E]
-//                  [--anti-aliasing on|off] [--samples N] [--seed S] [--device K] [--build host|device] [--dump-scene file] [--no-render] [--stats]
+//                  [--anti-aliasing on|off] [--samples N] [--seed S] [--device K | --devices 0,1,..] [--build host|device] [--dump-scene file] [--no-render] [--stats]
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -65,6 +65,7 @@ int main(int argc, char** argv) {
     }
     std::string scene_path, out = "render.png", dump;
     int device = 0;
+    std::vector<int> devices;
     long width = 0, height = 0, samples = -1;
     uint32_t max_depth = 5;
     float delta = 1e-5f;
@@ -87,6 +88,16 @@ int main(int argc, char** argv) {
         else if (a == "--samples") samples = std::atol(val().c_str());
         else if (a == "--seed") seed = std::atoll(val().c_str());
         else if (a == "--device") device = std::atoi(val().c_str());
+        else if (a == "--devices") {   // "0,1,2,3": one context over several GPUs (trr_create_multi)
+            std::string v = val();
+            size_t pos = 0;
+            while (pos <= v.size()) {
+                size_t c = v.find(',', pos);
+                if (c == std::string::npos) c = v.size();
+                if (c > pos) devices.push_back(std::atoi(v.substr(pos, c - pos).c_str()));
+                pos = c + 1;
+            }
+        }
         else if (a == "--build") {
             std::string b = val();
             if (b != "host" && b != "device") { std::fprintf(stderr, "error: --build takes host or device\n"); return 2; }
@@ -100,7 +111,7 @@ int main(int argc, char** argv) {
     }
     if (scene_path.empty()) {
         std::fprintf(stderr, "usage: %s <scene.yaml> [-o out.png|out.ppm] [--width W] [--height H] [--max-depth D] [--anti-aliasing on|off] "
-                             "[--samples N] [--seed S] [--device K] [--build host|device] [--dump-scene file] [--no-render] [--stats]\n", argv[0]);
+                             "[--samples N] [--seed S] [--device K | --devices 0,1,..] [--build host|device] [--dump-scene file] [--no-render] [--stats]\n", argv[0]);
         return 2;
     }
     Scene sc;
@@ -118,7 +129,8 @@ int main(int argc, char** argv) {
     if (!dump.empty()) dump_scene(sc, dump.c_str());
     if (no_render) return 0;
     try {
-        auto ctx = std::make_shared<Context>(device);   // throws when no HIP device exists: there is no CPU fallback
+        // throws when no HIP device exists: there is no CPU fallback
+        auto ctx = devices.empty() ? std::make_shared<Context>(device) : std::make_shared<Context>(devices);
         Raytracer rt(ctx, sc, delta, max_depth, build);
         Image im;
         im.width = rt.width(); im.height = rt.height();

@@ -181,6 +181,12 @@ public:
         int rc = trr_create(device, &ctx_);
         if (rc != TRR_OK) throw Error(rc, trr_last_error(nullptr));
     }
+    // several GPUs behind one context (trr_create_multi): scenes are replicated, whole-frame renders are sharded over the
+    // devices inside the library (block b -> device b % n, one RCCL gather, assembled on the first device)
+    explicit Context(const std::vector<int>& devices) {
+        int rc = trr_create_multi(devices.data(), (int)devices.size(), &ctx_);
+        if (rc != TRR_OK) throw Error(rc, trr_last_error(nullptr));
+    }
     ~Context() { trr_destroy(ctx_); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;

@@ -88,3 +88,18 @@ def test_cpp_cli_device_build_renders_the_same_frame(scene_dir, tmp_path):
     assert np.array_equal(out["host"], out["device"])
     p = subprocess.run([exe, scene_dir, "--build", "gpu"], capture_output=True, text=True, timeout=100)
     assert p.returncode == 2 and "host or device" in p.stderr
+
+
+def test_cpp_cli_over_a_multi_device_context_renders_the_same_frame(scene_dir, tmp_path):
+    """--devices 0: the C++ host layer's Context(devices) (trr_create_multi) with the one GPU of the test box, forced through
+    the RCCL gather; same bytes as the plain context."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "trr_cli")
+    out = {}
+    for name, extra, env in (("plain", ["--device", "0"], {}), ("multi", ["--devices", "0"], {"TRR_MULTI_FORCE_RCCL": "1"})):
+        png = os.path.join(str(tmp_path), name + ".png")
+        p = subprocess.run([exe, scene_dir, "-o", png, "--max-depth", "4"] + extra, capture_output=True, text=True, timeout=200,
+                           env={**os.environ, **env})
+        assert p.returncode == 0, p.stdout + p.stderr
+        out[name] = load_image_rgb8(png)
+    assert out["plain"].any() and np.array_equal(out["plain"], out["multi"])
