@@ -64,3 +64,23 @@ def test_every_schedule_and_layout_renders_the_same_bytes(ctx, spp):
         got, st = _render(ctx, sc, 5, env)
         assert np.array_equal(got, want), f"{name}, {spp} spp"
         assert st.rays() == st0.rays() and st.queue_overflows == 0, f"{name}, {spp} spp"
+
+
+@pytest.mark.parametrize("n_lights", [0, 1, 129])
+def test_light_counts_at_the_edges_of_the_shadow_entry_format(ctx, oracle_mod, n_lights):
+    """No light at all (no shadow rays), one, and 129 -- one more than the 16-byte compact shadow entries can name, so the
+    library falls back to 32-byte ray records by itself -- against the CPU oracle, levels and persistent schedules."""
+    from raytracing_amd.scene import Light
+    sc = standin.parity_scene(120, 80, detail=8)
+    rng = np.random.default_rng(n_lights)
+    sc.lights = [Light.from_ke((float(rng.uniform(-6, 6)), float(rng.uniform(1, 7)), float(rng.uniform(-6, 6))),
+                               (float(rng.uniform(0.2, 1)), float(rng.uniform(0.2, 1)), float(rng.uniform(0.2, 1))), float(rng.uniform(0.2, 2.0)))
+                 for _ in range(n_lights)]
+    osc = oracle_mod.OracleScene(sc)
+    ref = osc.render(shade=oracle_mod.SHADE_HOISTED, max_depth=3, want_ids=False, threads=8)
+    osc.close()
+    for env in ({"TRR_SCHEDULE": "levels"}, {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "0"}, {"TRR_SCHEDULE": "persistent"}):
+        got, st = _render(ctx, sc, 3, env)
+        d = np.abs(got.astype(np.int16) - ref["rgb"].astype(np.int16)).max(axis=-1)
+        assert (d <= 1).mean() >= 0.999, f"{n_lights} lights, {env}: exact on {(d == 0).mean():.6f}"
+        assert (st.rays_shadow == 0) == (n_lights == 0) and st.queue_overflows == 0
