@@ -142,7 +142,9 @@ int trr_create(int device_id, trr_ctx** out);
  * trr_render_blocks render block b on device b % N and bring the strips to the root with ONE ncclGather (RCCL over
  * xGMI; librccl is loaded on first use, a single-device context never needs it).  The Rust shim of INTEGRATION.md uses
  * all GPUs of a node by changing its trr_create call into this one.  trr_render_shard_device* and the hit-id buffers of
- * trr_render need a single-device context.  No counterpart in the reference (it has no device). */
+ * trr_render need a single-device context.  Environment: TRR_MULTI_TRANSPORT=copy exchanges the strips by peer copies
+ * instead of RCCL; TRR_MULTI_ALLOW_DUPLICATES=1 lets a device be listed twice (a rehearsal of the N-device path on one
+ * GPU; always peer copies).  No counterpart in the reference (it has no device). */
 int trr_create_multi(const int* device_ids, int n_devices, trr_ctx** out);
 int trr_device_count(const trr_ctx* ctx);   /* devices the context drives (1 for trr_create) */
 void trr_destroy(trr_ctx* ctx);

@@ -83,6 +83,7 @@ struct trr_ctx {
     // a multi-device context (trr_create_multi) owns one plain context per device and drives them; it has no streams or
     // work buffers of its own.  subs[0] is the root: it receives the gathered strips and assembles the frame.
     std::vector<trr_ctx*> subs;
+    bool duplicate_devices = false;      // (rehearsal on one GPU) a device is listed twice: strips are exchanged by peer copies
     std::vector<void*> comms;            // ncclComm_t per device (RCCL, loaded on demand); empty while no gather is needed
     DevBuf gathered;                     // on subs[0]'s device: the strips of all devices
     uint32_t rotate = 0;                 // round-robin start lane of single-batch frames
@@ -1843,7 +1844,12 @@ static int multi_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t ma
     }
     HIPCHK(ctx, hipSetDevice(root->device));
     if ((rc = ensure(root, root->frame, fb))) return fail(ctx, rc, root->err);
-    const bool use_rccl = n > 1 || std::getenv("TRR_MULTI_FORCE_RCCL") != nullptr;
+    // Strip exchange: one RCCL gather (default), or -- TRR_MULTI_TRANSPORT=copy, and always when a device is listed twice
+    // (rehearsals on one GPU: RCCL refuses duplicate devices) -- one peer copy per device into the root's gather buffer.
+    const char* e_tr = std::getenv("TRR_MULTI_TRANSPORT");
+    const bool use_copy = n > 1 && (ctx->duplicate_devices || (e_tr && e_tr[0] == 'c'));
+    const bool use_rccl = !use_copy && (n > 1 || std::getenv("TRR_MULTI_FORCE_RCCL") != nullptr);
+    if (use_copy && (rc = ensure(root, ctx->gathered, sb * n))) return fail(ctx, rc, root->err);
     if (use_rccl) {
         if ((rc = ensure(root, ctx->gathered, sb * n))) return fail(ctx, rc, root->err);
         if (ctx->comms.empty()) {
@@ -1907,6 +1913,15 @@ static int multi_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t ma
         if (e == 0) e = e2;
         if (e != 0) return fail(ctx, TRR_ERR_DEVICE, std::string("ncclGather: ") + r->GetErrorString(e));
         strips = ctx->gathered.p;
+    } else if (use_copy) {
+        for (uint32_t d = 0; d < n; ++d) {
+            trr_ctx* c = ctx->subs[d];
+            HIPCHK(ctx, hipSetDevice(c->device));
+            HIPCHK(ctx, hipMemcpyPeerAsync((uint8_t*)ctx->gathered.p + (size_t)d * sb, root->device, c->strip.p, c->device, sb, c->stream));
+            HIPCHK(ctx, hipEventRecord(c->fork, c->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(root->stream, c->fork, 0));   // (a no-op for the root's own stream)
+        }
+        strips = ctx->gathered.p;
     }
     HIPCHK(ctx, hipSetDevice(root->device));
     launch_assemble(root->stream, w, h, t.bw, t.bh, t.nbx, t.nby, n, sb, (const uint8_t*)strips, (uint8_t*)root->frame.p);
@@ -1940,11 +1955,16 @@ int trr_create_multi(const int* device_ids, int n_devices, trr_ctx** out) {
     if (!out) return fail(nullptr, TRR_ERR_INVALID, "trr_create_multi: out is NULL");
     *out = nullptr;
     if (!device_ids || n_devices <= 0 || n_devices > 64) return fail(nullptr, TRR_ERR_INVALID, "trr_create_multi: need 1..64 device ids");
+    // a device listed twice: refused, unless TRR_MULTI_ALLOW_DUPLICATES is set -- several sub-contexts on one GPU rehearse the
+    // N-device logic (sharding, host threads, strip exchange by peer copies, assembly) where only one GPU exists
+    bool dup = false;
     for (int a = 0; a < n_devices; ++a)
         for (int b = a + 1; b < n_devices; ++b)
-            if (device_ids[a] == device_ids[b]) return fail(nullptr, TRR_ERR_INVALID, "trr_create_multi: a device is listed twice");
+            if (device_ids[a] == device_ids[b]) dup = true;
+    if (dup && !std::getenv("TRR_MULTI_ALLOW_DUPLICATES")) return fail(nullptr, TRR_ERR_INVALID, "trr_create_multi: a device is listed twice");
     DeviceGuard guard;
     trr_ctx* ctx = new trr_ctx();
+    ctx->duplicate_devices = dup;
     ctx->device = device_ids[0];
     for (int k = 0; k < n_devices; ++k) {
         trr_ctx* c = nullptr;

@@ -62,3 +62,41 @@ def test_multi_context_argument_checks():
         Context(devices=[])
     with pytest.raises(N.NativeError):
         Context(devices=[4096])
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_n_device_logic_rehearsed_on_one_gpu(monkeypatch, n):
+    """TRR_MULTI_ALLOW_DUPLICATES: n sub-contexts on the one GPU of the test box run the whole N-device path of the library --
+    scene replicas, shard n of N per sub-context (host threads when progress is polled), strips exchanged by peer copies
+    (RCCL refuses a device listed twice), assembly on the root -- against the plain context, byte for byte."""
+    import ctypes as C
+    sc = standin.parity_scene(330, 250, detail=10)   # 330 x 250: a remainder strip on both edges, 400 blocks of 16 x 12
+    plain = Context(0)
+    rt = Raytracer(sc, max_depth=3, context=plain)
+    want = rt.render_frame(want_ids=True)
+    rt.close()
+    plain.close()
+    monkeypatch.setenv("TRR_MULTI_ALLOW_DUPLICATES", "1")
+    multi = Context(devices=[0] * n)
+    try:
+        assert multi.device_count == n
+        rt = Raytracer(sc, max_depth=3, context=multi)
+        out = rt.render_frame()   # not polled: the shards are queued from one thread
+        assert np.array_equal(out["rgb"], want["rgb"])
+        assert out["stats"].rays() == want["stats"].rays() and out["stats"].blocks_rendered == 400
+        calls = []
+        out = rt.render_frame(progress=lambda done, total: calls.append((done, total)))   # polled: one host thread per device
+        assert np.array_equal(out["rgb"], want["rgb"])
+        assert calls and calls[-1] == (400, 400) and all(a[0] <= b[0] for a, b in zip(calls, calls[1:]))
+        blocks = {}
+        rt.render_blocks(lambda xb, yb, blk: blocks.__setitem__((xb, yb), blk.copy()), blocks_per_batch=37)
+        assert len(blocks) == 400
+        bh, bw = 250 // 20, 330 // 20
+        for (xb, yb), blk in blocks.items():
+            assert np.array_equal(blk, want["rgb"][yb * bh:(yb + 1) * bh, xb * bw:(xb + 1) * bw])
+        flag = C.c_int32(1)   # cancelled before the first batch on every device
+        assert rt.render_frame(cancel_flag=flag)["cancelled"]
+        assert np.array_equal(rt.render_frame()["rgb"], want["rgb"])   # and the context is usable afterwards
+        rt.close()
+    finally:
+        multi.close()
