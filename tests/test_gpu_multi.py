@@ -81,7 +81,7 @@ def test_n_device_logic_rehearsed_on_one_gpu(monkeypatch, n):
     try:
         assert multi.device_count == n
         rt = Raytracer(sc, max_depth=3, context=multi)
-        out = rt.render_frame()   # not polled: the shards are queued from one thread
+        out = rt.render_frame()   # not polled: the host threads only queue the shards
         assert np.array_equal(out["rgb"], want["rgb"])
         assert out["stats"].rays() == want["stats"].rays() and out["stats"].blocks_rendered == 400
         calls = []
