@@ -21,6 +21,13 @@ Roofline: the path is fp32 VALU work on cache-resident dat
 the roof is the fp32 vector peak.  `achieved` = ALGORITHMIC flops of a frame / frame time, the flops from the counter
 build's measured unit counts times the per-unit constants below; nothing in the line can imply more than a peak.
 """
+import os as _os
+
+# More hardware queues than HIP's default of 4 (which the GPU box also exports): the library runs up to nine streams per
+# frame (DESIGN.md section 4).  Must be in the environment before the HIP runtime starts, i.e. before torch touches the GPU.
+if int(_os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 16:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "16"
+
 import argparse
 import json
 import os

@@ -68,8 +68,10 @@ struct trr_ctx {
     // Batches of blocks are pipelined over MAX_LANES work sets, each with its own stream: the persistent trace kernels
     // of one batch drain (few long rays left) while the next batch's kernels fill the freed CUs.
     struct WorkSet {
-        DevBuf hits, level, term, nlev, color, occ, wqueue, gqueue, shadow_q, chain_q[2], counters, spill;
+        DevBuf hits, level, term, nlev, color, occ, wqueue, gqueue, shadow_q, shadow_deep[2], chain_q[2], counters, spill;
         hipStream_t stream = nullptr;
+        hipStream_t aux[2] = {nullptr, nullptr};   // split schedule: level 0's shadow rays / the deeper levels' shadow rays
+        std::vector<hipEvent_t> sync_ev;           // split schedule: [2 l] level l set up, [2 l + 1] level l's shadow rays traced
         hipEvent_t done = nullptr;
     };
     static constexpr int MAX_LANES = 6;
@@ -108,12 +110,18 @@ struct trr_ctx {
     std::vector<PendingStats> pending;
 };
 
+// HIP's default of 4 hardware queues per process is fewer than the streams a frame uses (up to three lanes, each with two
+// more streams in the split schedule): ask for 16 when this library is loaded before the HIP runtime starts and the host has
+// not chosen a value itself.
+static const int g_hw_queues_env = [] { return ::setenv("GPU_MAX_HW_QUEUES", "16", 0); }();
+
 struct trr_scene {
     trr_ctx* ctx = nullptr;
     int device = 0;                      // ctx->device, kept so that trr_scene_destroy does not touch the context
     std::vector<trr_scene*> replicas;    // scene of a multi-device context: one uploaded copy per device, nothing else
     DevBuf nodes, qnodes, tris, interp, objs, mats, texs, texels, lights, sky;
     bool quantised = false;              // qnodes holds the 64-B form of every node (kernels.hip: k_quantise_nodes)
+    bool any_reflective = true;          // some material is a mirror (illum 3 / 4, material.rs:47-49): reflection rays can exist
     std::vector<ObjRec> h_objs;
     uint32_t n_objs = 0, n_lights = 0, n_mats = 0, n_tex = 0;
     uint64_t n_nodes = 0, n_tris_total = 0, n_tris_live = 0;
@@ -224,6 +232,8 @@ int trr_create(int device_id, trr_ctx** out) {
     }
     for (auto& w : ctx->ws) {
         if (hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&w.aux[0], hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&w.aux[1], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) {
             trr_destroy(ctx);
             return fail(nullptr, TRR_ERR_DEVICE, "hipStreamCreate / hipEventCreate for a work set failed");
@@ -254,9 +264,12 @@ void trr_destroy(trr_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto& w : ctx->ws) {
-        for (DevBuf* b : {&w.hits, &w.level, &w.term, &w.nlev, &w.color, &w.occ, &w.wqueue, &w.gqueue, &w.shadow_q, &w.chain_q[0], &w.chain_q[1], &w.counters, &w.spill})
+        for (DevBuf* b : {&w.hits, &w.level, &w.term, &w.nlev, &w.color, &w.occ, &w.wqueue, &w.gqueue, &w.shadow_q, &w.shadow_deep[0], &w.shadow_deep[1],
+                          &w.chain_q[0], &w.chain_q[1], &w.counters, &w.spill})
             release(*b);
+        for (hipEvent_t ev : w.sync_ev) (void)hipEventDestroy(ev);
         if (w.done) (void)hipEventDestroy(w.done);
+        for (hipStream_t a : w.aux) if (a) (void)hipStreamDestroy(a);
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     if (ctx->fork) (void)hipEventDestroy(ctx->fork);
@@ -666,6 +679,8 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
     sc->bvh_depth = depth_max;
     sc->stack_need = stack_max;
     sc->n_mats = (uint32_t)mats.size();
+    sc->any_reflective = false;
+    for (const MatRec& m : mats) sc->any_reflective = sc->any_reflective || m.illum == 3 || m.illum == 4;
     sc->n_tex = n_textures;
     // texture atlas
     std::vector<TexRec> texs(n_textures);
@@ -949,11 +964,12 @@ static hipEvent_t get_event(trr_ctx* ctx, size_t i) {
     return ctx->events[i];
 }
 
-// counters block of one batch (uint32 words, cleared by ONE memset): [CW_WORK + 8 i ..] work counters (one per XCD segment) of the batch's i-th trace
+// counters block of one batch (uint32 words, cleared by ONE memset): [CW_WORK + 8 i ..] work counters (one per XCD segment) of the batch's trace launch number i (split schedule: camera
+// rays 0, reflection rays of level l 2 l - 1, shadow rays of level l 2 l + 2; up to 520), [CW_ZERO] a word nobody writes,
 // launch (work items claimed), [CW_NSHADOW + lvl] / [CW_NCHAIN + lvl] shadow rays emitted at / chain rays entering level
 // lvl (level-synchronous schedule), [CW_SPILL + k] entries spilled by launch k (persistent schedule); the 64-bit kernel
 // counters (device_types.h KC_*) follow at byte offset CW_WORDS*4.
-enum { CW_WORK = 0, CW_WORK_STRIDE = 8, CW_NSHADOW = 2304, CW_NCHAIN = 2592, CW_SPILL = 2880, CW_WORDS = 3200 };
+enum { CW_WORK = 0, CW_WORK_STRIDE = 8, CW_NSHADOW = 4160, CW_NCHAIN = 4448, CW_SPILL = 4736, CW_ZERO = 5024, CW_WORDS = 5120 };
 static constexpr uint32_t MAX_FOLLOWUPS = 7;
 static constexpr size_t RB_STRIDE = CW_WORDS * 4 + 8 * 16;   // per batch: launch / queue counters + up to 16 kernel counters
 static_assert(KC_COUNT <= 16, "kernel counters outgrew the read-back block");
@@ -1017,7 +1033,10 @@ struct WorkView {
     float4* wqueue = nullptr;   // wave-local ray queues of the trace grid (32-B entries)
     float4* gqueue = nullptr;   // two device-wide spill queues of spill_capacity() entries each (ping-pong between launches)
     // level-synchronous schedule
-    float4* shadow_q = nullptr;     // [cap * L] 32-B ray records of one level's shadow rays
+    float4* shadow_q = nullptr;     // [cap * L] one level's shadow rays (16-B compact entries or 32-B ray records)
+    float4* shadow_deep[2] = {nullptr, nullptr};   // split schedule: the shadow rays of the odd / even levels >= 1
+    hipStream_t aux[2] = {nullptr, nullptr};       // split schedule (nullptr: not available, e.g. the no-alloc entry point)
+    hipEvent_t* sync_ev = nullptr;                 // split schedule: 2 * max_depth events
     float4* chain_q[2] = {nullptr, nullptr};   // [cap] reflection rays entering the even / odd levels
     void* counters = nullptr;   // RB_STRIDE bytes: work counter + kernel counters
     uint2* spill = nullptr;
@@ -1054,6 +1073,8 @@ struct BatchGrids {
     uint32_t followups;        // persistent: launches after the first that drain what the launch before spilled (0 = none)
     uint32_t chunk_min[2];     // persistent: smallest claim of work items per wavefront in the first / the follow-up launches
     uint32_t raygen, secondary;   // levels: grids of the camera-ray and the secondary-ray launches
+    uint32_t levels;              // levels: chain levels that can hold a hit (1 when no material is a mirror, else max_depth)
+    uint32_t split;               // levels: 1 = reflection rays and shadow rays in launches of their own, on streams of their own
     uint32_t drain_level;         // levels: from this level's set-up on, ONE k_trace launch (grid `trace`) drains the rest of the
                                   // batch -- the level's shadow rays, the next level's reflection rays and all they spawn
                                   // (NO_DRAIN: never)
@@ -1114,8 +1135,68 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
         ev_begin(0, s_);
         launch_trace_level(true, count, g.raygen, s_, fp, bp, tio);
         ev_end(s_);
+        const uint32_t n_levels = std::min(fp.max_depth, std::max(1u, g.levels));   // deeper levels would find empty queues
+        if (g.split != 0u && n_levels >= 1u && w.aux[0] != nullptr && w.sync_ev != nullptr) {
+            // ---- split schedule.  Only the reflection rays carry the chain on: level l + 1's hit set-up needs their hits
+            // and nothing of level l's shadow rays, which are the bulk.  So the main stream runs the thin dependent chain
+            //     camera rays -> set-up 0 -> reflection rays 1 -> set-up 1 -> reflection rays 2 -> ... -> resolve
+            // and every level's shadow rays go to a launch of their own on another stream as soon as that level is set
+            // up (level 0's on aux[0], the deeper levels' on aux[1]): the deep levels finish while level 0's shadow rays
+            // are still being traced, instead of after them.  Shadow queues: level 0 has its own, the deeper levels
+            // alternate between two (level l + 2's set-up waits for level l's shadow launch).
+            const char* e_shadow = std::getenv("TRR_SHADOW");
+            const bool wide_shadow = e_shadow && e_shadow[0] == 'w';
+            const uint32_t compact = (!wide_shadow && fp.n_lights <= 128u && bp.cap <= (1u << 25)) ? 1u : 0u;
+            hipEvent_t last_aux[2] = {nullptr, nullptr};
+            for (uint32_t lvl = 0; lvl < n_levels; ++lvl) {
+                float4* sq = lvl == 0 ? w.shadow_q : w.shadow_deep[(lvl - 1) & 1];
+                if (lvl >= 3) (void)hipStreamWaitEvent(s_, w.sync_ev[2 * (lvl - 2) + 1], 0);   // the queue's previous user is done
+                SetupIO sio{};
+                sio.chain_in = w.chain_q[lvl & 1];
+                sio.n_chain_in = cw + CW_NCHAIN + lvl;
+                sio.hits = w.hits; sio.level = w.level; sio.term = w.term; sio.nlev = w.nlev;
+                sio.shadow_compact = compact;
+                sio.shadow_out = sq;
+                sio.n_shadow_out = cw + CW_NSHADOW + lvl;
+                sio.chain_out = w.chain_q[(lvl + 1) & 1];
+                sio.n_chain_out = cw + CW_NCHAIN + lvl + 1;
+                sio.counters = kc;
+                ev_begin(1, s_);
+                launch_setup(lvl == 0, aux_grid, s_, fp, bp, sio, lvl);
+                ev_end(s_);
+                (void)hipEventRecord(w.sync_ev[2 * lvl], s_);
+                // this level's shadow rays, off the chain
+                hipStream_t sa = w.aux[lvl == 0 ? 0 : 1];
+                (void)hipStreamWaitEvent(sa, w.sync_ev[2 * lvl], 0);
+                LevelIO ts = tio;
+                ts.shadow_q = sq; ts.shadow_compact = compact; ts.shadow_level = lvl;
+                ts.n_shadow = cw + CW_NSHADOW + lvl;
+                ts.chain_q = nullptr; ts.n_chain = cw + CW_ZERO;
+                ts.work_counter = cw + CW_WORK + CW_WORK_STRIDE * (2 * lvl + 2);
+                ts.first_obj = nullptr; ts.first_tri = nullptr;
+                ev_begin(0, sa);
+                launch_trace_level(false, count, g.secondary, sa, fp, bp, ts);
+                ev_end(sa);
+                (void)hipEventRecord(w.sync_ev[2 * lvl + 1], sa);
+                last_aux[lvl == 0 ? 0 : 1] = w.sync_ev[2 * lvl + 1];
+                // the next level's reflection rays, on the chain
+                if (lvl + 1 < n_levels) {
+                    LevelIO tc = tio;
+                    tc.shadow_q = nullptr; tc.n_shadow = cw + CW_ZERO; tc.shadow_compact = 0; tc.shadow_level = 0;
+                    tc.chain_q = w.chain_q[(lvl + 1) & 1];
+                    tc.n_chain = cw + CW_NCHAIN + lvl + 1;
+                    tc.work_counter = cw + CW_WORK + CW_WORK_STRIDE * (2 * lvl + 1);
+                    tc.first_obj = nullptr; tc.first_tri = nullptr;
+                    ev_begin(0, s_);
+                    launch_trace_level(false, count, g.secondary, s_, fp, bp, tc);
+                    ev_end(s_);
+                }
+            }
+            for (hipEvent_t e : last_aux)
+                if (e) (void)hipStreamWaitEvent(s_, e, 0);   // the resolve pass needs every occluder code
+        } else
         // max_depth == 0: one set-up pass turns every sample into skybox(ray.direction) (mod.rs:125-127), no secondary rays
-        for (uint32_t lvl = 0; lvl < std::max(1u, fp.max_depth); ++lvl) {
+        for (uint32_t lvl = 0; lvl < std::max(1u, n_levels); ++lvl) {
             SetupIO sio{};
             sio.chain_in = w.chain_q[lvl & 1];
             sio.n_chain_in = cw + CW_NCHAIN + lvl;
@@ -1138,7 +1219,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
             launch_setup(lvl == 0, aux_grid, s_, fp, bp, sio, lvl);
             ev_end(s_);
             if (fp.max_depth == 0) break;
-            if (lvl >= g.drain_level && lvl + 1 < fp.max_depth) {
+            if (lvl >= g.drain_level && lvl + 1 < n_levels) {
                 // levels-then-drain: the deep levels hold few rays each, and a launch per level costs a ramp-up and a tail
                 // as long as its slowest ray (a march through glass, a long reflection path) whatever it holds.  k_trace
                 // takes this level's shadow rays and the next level's reflection rays as its work items and follows
@@ -1241,7 +1322,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     const uint32_t schedule = choose_schedule((uint64_t)n_owned * spb, L, max_depth);
     const uint64_t per_sample = sizeof(HitRec) + 16ull * LEVEL_F4 * std::max(1u, max_depth) + 16 + 1 + 12 +
                                 4ull * std::max(1u, L) * std::max(1u, max_depth) + 16 +
-                                (schedule == SCHED_LEVELS ? 32ull * std::max(1u, L) + 64 : 0);
+                                (schedule == SCHED_LEVELS ? 3 * 32ull * std::max(1u, L) + 64 : 0);   // three shadow queues (split schedule)
     // Batch count (measured on MI355X, scripts/experiments/sweep_batches.py): few, large batches -- every persistent launch pays a
     // ramp-up and a tail of fixed length -- but at least two, on two lanes, so that one batch's tails and small deep-level
     // launches overlap the other's bulk; three lanes once there are four or more batches.  An odd batch per lane keeps
@@ -1320,15 +1401,30 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     // eighth of it 5.64 / 5.42, 4K mirrors max_depth 9 15.8 / 14.9): a caller that waits for every frame gains what the
     // thin deep levels' launch tails cost; one that keeps two frames in flight (TRR_FLAG_PIPELINED) already hides those
     // tails behind the other frame and only pays k_trace's dearer rays (30.6 / 31.3, 12.3 / 13.4), so it keeps the levels.
+    grids.levels = sc->any_reflective ? max_depth : std::min(max_depth, 1u);
+    // Split schedule (queue_batch): every level's shadow rays on a stream of their own, off the chain of reflection rays.  It
+    // needs more concurrent streams than HIP's default of 4 hardware queues carries -- with 4, streams of different lanes
+    // share a queue and whole batches serialise (an eighth of the 4K x 16 spp frame 5.7 instead of 5.4 ms) -- so it is
+    // used only when GPU_MAX_HW_QUEUES says there are at least 8 (the library asks for 16 when it is loaded before HIP
+    // starts; bench.py and the tests set it), and for frames or shards of at most 2^26 samples: measured with 16 queues,
+    // without / with the split, lone frame: an eighth of the 4K x 16 spp frame 5.44 / 5.17 ms, a quarter 9.05 / 8.71, a
+    // half 16.3 / 16.0, 4K mirrors max_depth 9 15.4 / 14.5; the whole frame 29.9 / 30.8 (nine persistent launches at once
+    // crowd each other), so it keeps the plain levels.  TRR_SPLIT=0|1 overrides.
+    {
+        const char* e_q = std::getenv("GPU_MAX_HW_QUEUES");
+        const int hw_queues = e_q ? std::atoi(e_q) : 4;
+        grids.split = (hw_queues >= 8 && total_samples <= (1ull << 26) && grids.levels >= 2) ? 1u : 0u;
+    }
+    if (const char* e = std::getenv("TRR_SPLIT")) grids.split = std::atoi(e) != 0 ? 1u : 0u;
     grids.drain_level = (flags & TRR_FLAG_PIPELINED) ? NO_DRAIN : 2u;
     if (const char* e = std::getenv("TRR_DRAIN_LEVEL")) grids.drain_level = std::atoi(e) < 0 ? NO_DRAIN : (uint32_t)std::atoi(e);
-    const bool drains = schedule == SCHED_LEVELS && grids.drain_level != NO_DRAIN && grids.drain_level + 1 < max_depth;
+    const bool drains = schedule == SCHED_LEVELS && grids.split == 0 && grids.drain_level != NO_DRAIN && grids.drain_level + 1 < max_depth;
     const uint32_t trace_grid = schedule == SCHED_PERSISTENT ? grids.trace
                                                              : std::max(std::max(grids.raygen, grids.secondary), drains ? grids.trace : 0u);   // sizes the stack-spill area
     if (std::getenv("TRR_DEBUG"))
-        std::fprintf(stderr, "trr: schedule %s, resident blocks per CU persistent %d raygen %d secondary %d, lanes %u batches %llu\n",
-                     schedule == SCHED_LEVELS ? "levels" : "persistent", ctx->bpc[cb], ctx->bpc_level[1][cb], ctx->bpc_level[0][cb], lanes,
-                     (unsigned long long)want_batches);
+        std::fprintf(stderr, "trr: schedule %s%s, levels %u, resident blocks per CU persistent %d raygen %d secondary %d, lanes %u batches %llu\n",
+                     schedule == SCHED_LEVELS ? "levels" : "persistent", grids.split ? " (split)" : "", grids.levels, ctx->bpc[cb],
+                     ctx->bpc_level[1][cb], ctx->bpc_level[0][cb], lanes, (unsigned long long)want_batches);
     const uint32_t qcap = queue_capacity(L);
     int rc;
     // `pool` work sets may be used by this call: its `lanes` consecutive ones starting at lane_base.  A single-batch frame
@@ -1352,8 +1448,17 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
                 (rc = ensure(ctx, w.gqueue, grids.followups ? 2 * (size_t)spill_capacity(trace_grid, L) * 32 : 256)))
                 return rc;
         } else {
+            const bool split_bufs = grids.split != 0 && max_depth >= 2;
+            if (grids.split != 0)
+                while (w.sync_ev.size() < 2 * (size_t)D + 2) {
+                    hipEvent_t ev = nullptr;
+                    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(ctx, TRR_ERR_DEVICE, "hipEventCreate failed");
+                    w.sync_ev.push_back(ev);
+                }
             if ((rc = ensure(ctx, w.shadow_q, (size_t)cap * 32 * std::max(1u, L))) || (rc = ensure(ctx, w.chain_q[0], (size_t)cap * 32)) ||
                 (rc = ensure(ctx, w.chain_q[1], (size_t)cap * 32)) ||
+                (split_bufs && ((rc = ensure(ctx, w.shadow_deep[0], (size_t)cap * 32 * std::max(1u, L))) ||
+                                (max_depth >= 3 && (rc = ensure(ctx, w.shadow_deep[1], (size_t)cap * 32 * std::max(1u, L)))))) ||
                 (drains && (rc = ensure(ctx, w.wqueue, trace_queue_bytes(grids.trace, qcap)))))
                 return rc;
         }
@@ -1444,6 +1549,9 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         wv.hits = (HitRec*)w.hits.p; wv.level = (float4*)w.level.p; wv.term = (float4*)w.term.p; wv.nlev = (uint8_t*)w.nlev.p; wv.color = (float*)w.color.p;
         wv.occ = (int32_t*)w.occ.p; wv.wqueue = (float4*)w.wqueue.p; wv.gqueue = (float4*)w.gqueue.p; wv.shadow_q = (float4*)w.shadow_q.p;
         wv.chain_q[0] = (float4*)w.chain_q[0].p; wv.chain_q[1] = (float4*)w.chain_q[1].p; wv.counters = w.counters.p; wv.spill = (uint2*)w.spill.p;
+        wv.shadow_deep[0] = (float4*)w.shadow_deep[0].p; wv.shadow_deep[1] = (float4*)w.shadow_deep[1].p;
+        wv.aux[0] = w.aux[0]; wv.aux[1] = w.aux[1];
+        wv.sync_ev = w.sync_ev.empty() ? nullptr : w.sync_ev.data();
         queue_batch(fp, bp, wv, grids, count, strip_dev, ids_obj_dev, ids_tri_dev, s_, ev_begin, ev_end);
         if (!chk(hipGetLastError(), "kernel launch")) break;
         if (stats && !chk(hipMemcpyAsync(pinned_base + rb_stride * bi, w.counters.p, rb_stride, hipMemcpyDeviceToHost, s_), "hipMemcpyAsync")) break;
@@ -1594,6 +1702,7 @@ int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, ui
     grids.aux_max = n_cu * 8;
     grids.followups = 0;
     grids.drain_level = NO_DRAIN;   // (the drain's ray queues would take scratch from the batch)
+    grids.levels = sc->any_reflective ? max_depth : std::min(max_depth, 1u);
     grids.chunk_min[0] = 64; grids.chunk_min[1] = 16;
     const uint32_t spill_grid = schedule == SCHED_PERSISTENT ? grids.trace : grids.raygen;
     // the largest whole number of blocks per batch whose work set fits the scratch array

@@ -4,6 +4,9 @@ difference beyond the north_star bar.  Usage: python scripts/experiments/fuzz_pa
 import os
 import sys
 
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 16:
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"   # before the HIP runtime starts
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 from oracle import oracle  # noqa: E402
@@ -18,7 +21,8 @@ ENVS = [
     {}, {"TRR_SCHEDULE": "levels"}, {"TRR_SCHEDULE": "persistent"}, {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "0"},
     {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "1"}, {"TRR_SCHEDULE": "levels", "TRR_SHADOW": "wide"},
     {"TRR_SCHEDULE": "levels", "TRR_NODES": "quantised"}, {"TRR_SCHEDULE": "levels", "TRR_BATCHES": "3"},
-    {"TRR_SCHEDULE": "levels", "TRR_RESOLVE": "two_pass"},
+    {"TRR_SCHEDULE": "levels", "TRR_RESOLVE": "two_pass"}, {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1"},
+    {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "0", "TRR_DRAIN_LEVEL": "1"}, {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1", "TRR_SHADOW": "wide"},
 ]
 KEYS = sorted({k for e in ENVS for k in e})
 ctx = Context(0)

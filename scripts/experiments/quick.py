@@ -1,5 +1,12 @@
 """Quick timing of the stand-in configurations and of a 1/8 shard sequence (one GPU, no CPU baseline).
 Usage: python scripts/experiments/quick.py [configs, e.g. 2,3,s8]  -> one line per item: ms per frame."""
+import os as _os
+
+# More hardware queues than HIP's default of 4 (which the GPU box also exports): the library runs up to nine streams per
+# frame.  Must be in the environment before the HIP runtime starts, i.e. before torch touches the GPU.
+if int(_os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 16:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "16"
+
 import hashlib
 import os
 import sys

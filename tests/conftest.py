@@ -1,3 +1,10 @@
+import os as _os
+
+# More hardware queues than HIP's default of 4 (which the GPU box also exports): the library runs up to nine streams per
+# frame.  Must be in the environment before the HIP runtime starts, i.e. before torch touches the GPU.
+if int(_os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 16:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "16"
+
 import os
 import sys
 

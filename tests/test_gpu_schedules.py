@@ -21,7 +21,7 @@ def ctx():
 
 
 def _render(ctx, sc, max_depth, env):
-    keys = ("TRR_SCHEDULE", "TRR_DRAIN_LEVEL", "TRR_SHADOW", "TRR_RESOLVE", "TRR_BATCHES")
+    keys = ("TRR_SCHEDULE", "TRR_DRAIN_LEVEL", "TRR_SHADOW", "TRR_RESOLVE", "TRR_BATCHES", "TRR_SPLIT")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)
@@ -43,12 +43,15 @@ def _render(ctx, sc, max_depth, env):
 
 VARIANTS = {
     "persistent": {"TRR_SCHEDULE": "persistent"},
-    "levels, no drain": {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "-1"},
-    "levels, drain from level 0": {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "0"},
-    "levels, drain from level 1": {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "1"},
-    "levels, drain from level 3": {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "3"},
-    "levels, wide shadow records": {"TRR_SCHEDULE": "levels", "TRR_SHADOW": "wide"},
-    "levels, wide shadow records, drain from level 0": {"TRR_SCHEDULE": "levels", "TRR_SHADOW": "wide", "TRR_DRAIN_LEVEL": "0"},
+    "levels, split (shadow rays on streams of their own)": {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1"},
+    "levels, split, wide shadow records": {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1", "TRR_SHADOW": "wide"},
+    "levels, split, three batches": {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1", "TRR_BATCHES": "3"},
+    "levels, no split, no drain": {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "0", "TRR_DRAIN_LEVEL": "-1"},
+    "levels, drain from level 0": {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "0", "TRR_SPLIT": "0"},
+    "levels, drain from level 1": {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "1", "TRR_SPLIT": "0"},
+    "levels, drain from level 3": {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "3", "TRR_SPLIT": "0"},
+    "levels, wide shadow records": {"TRR_SCHEDULE": "levels", "TRR_SHADOW": "wide", "TRR_SPLIT": "0"},
+    "levels, wide shadow records, drain from level 0": {"TRR_SCHEDULE": "levels", "TRR_SHADOW": "wide", "TRR_DRAIN_LEVEL": "0", "TRR_SPLIT": "0"},
     "levels, two resolve passes": {"TRR_SCHEDULE": "levels", "TRR_RESOLVE": "two_pass"},
     "levels, five batches": {"TRR_SCHEDULE": "levels", "TRR_BATCHES": "5"},
 }
@@ -58,7 +61,7 @@ VARIANTS = {
 def test_every_schedule_and_layout_renders_the_same_bytes(ctx, spp):
     sc = standin.parity_scene(320, 240, detail=14)
     sc.settings.anti_aliasing, sc.settings.samples = spp > 1, spp
-    want, st0 = _render(ctx, sc, 5, {"TRR_SCHEDULE": "levels"})
+    want, st0 = _render(ctx, sc, 5, {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "0"})
     assert want.any() and st0.rays_reflection > 0 and st0.rays_shadow > 0
     for name, env in VARIANTS.items():
         got, st = _render(ctx, sc, 5, env)
@@ -79,7 +82,8 @@ def test_light_counts_at_the_edges_of_the_shadow_entry_format(ctx, oracle_mod, n
     osc = oracle_mod.OracleScene(sc)
     ref = osc.render(shade=oracle_mod.SHADE_HOISTED, max_depth=3, want_ids=False, threads=8)
     osc.close()
-    for env in ({"TRR_SCHEDULE": "levels"}, {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "0"}, {"TRR_SCHEDULE": "persistent"}):
+    for env in ({"TRR_SCHEDULE": "levels", "TRR_SPLIT": "0"}, {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1"},
+                {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "0", "TRR_DRAIN_LEVEL": "0"}, {"TRR_SCHEDULE": "persistent"}):
         got, st = _render(ctx, sc, 3, env)
         d = np.abs(got.astype(np.int16) - ref["rgb"].astype(np.int16)).max(axis=-1)
         assert (d <= 1).mean() >= 0.999, f"{n_lights} lights, {env}: exact on {(d == 0).mean():.6f}"
