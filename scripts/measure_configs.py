@@ -6,6 +6,11 @@ ray accounting of SURVEY.md 8(d).  CPU: oracle/ in reference-literal mode on eve
 sample holds about 30 M rays), all host threads the box grants, credited the GPU's ray count for the same blocks; the
 sampled blocks are compared byte for byte.  Writes one JSON line per configuration.
 Usage (GPU box): python scripts/measure_configs.py [--configs 1,2,3,4,5] > gpurun_out/configs.jsonl"""
+import os as _os
+
+if int(_os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 16:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "16"   # before the HIP runtime starts (DESIGN.md section 4)
+
 import argparse
 import json
 import os
@@ -64,9 +69,9 @@ def main():
         best = 1e30
         for _ in range(2):
             t0 = time.perf_counter()
-            for _k in range(args.frames):
+            for _k in range(args.frames):   # one frame at a time, as the reference's user gets them (render.rs:39-71)
                 rt.render_shard_device(0, 1, strip.data_ptr(), sb, stream=stream.cuda_stream)
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) / args.frames)
         cst = N.Stats()
         rt.render_shard_device(0, 1, strip.data_ptr(), sb, stream=stream.cuda_stream, stats=cst, counters=True)
