@@ -1,7 +1,10 @@
 """Renders K frames of a 1/N shard of the bench workload, one after the other (host sync between frames); meant to run under
-`rocprofv3 --kernel-trace` to see where a small shard's frame time goes.  Usage: shard_trace.py N K [config: 3 (default) | 2 | 5]"""
+`rocprofv3 --kernel-trace` to see where a small shard's frame time goes.  Usage: shard_trace.py N K [config: 3 (default) | 1 | 2 | 4 | 5]"""
 import os
 import sys
+
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 16:
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"   # before the HIP runtime starts
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
@@ -13,6 +16,10 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 c = sys.argv[3] if len(sys.argv) > 3 else "3"
 if c == "2":
     rt = Raytracer(standin.standin_car(1920, 1080), max_depth=5)
+elif c == "1":
+    rt = Raytracer(standin.standin_test(800, 600), max_depth=2)
+elif c == "4":
+    rt = Raytracer(standin.standin_terrain(3840, 2160), max_depth=5)
 elif c == "5":
     rt = Raytracer(standin.standin_mirrors(3840, 2160), max_depth=9)
 else:

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Measures the five BASELINE.json configurations on ONE GPU (stand-in scenes) next to the CPU restatement.
 
-GPU: ms/frame of a sequence of frames (device-resident, no host synchronisation between frames) and Mrays/s with the
-ray accounting of SURVEY.md 8(d).  CPU: oracle/ in reference-literal mode on every k-th block (k chosen so that the
+GPU: ms per frame, one frame at a time (device-resident output, host synchronisation after every frame, after half a second
+of warm-up frames so that the clocks are up) and Mrays/s with the ray accounting of SURVEY.md 8(d).  CPU: oracle/ in reference-literal mode on every k-th block (k chosen so that the
 sample holds about 30 M rays), all host threads the box grants, credited the GPU's ray count for the same blocks; the
 sampled blocks are compared byte for byte.  Writes one JSON line per configuration.
 Usage (GPU box): python scripts/measure_configs.py [--configs 1,2,3,4,5] > gpurun_out/configs.jsonl"""
@@ -66,8 +66,12 @@ def main():
         st = N.Stats()
         rt.render_shard_device(0, 1, strip.data_ptr(), sb, stream=stream.cuda_stream, stats=st)
         torch.cuda.synchronize()
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < 0.5:
+            rt.render_shard_device(0, 1, strip.data_ptr(), sb, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
         best = 1e30
-        for _ in range(2):
+        for _ in range(3):
             t0 = time.perf_counter()
             for _k in range(args.frames):   # one frame at a time, as the reference's user gets them (render.rs:39-71)
                 rt.render_shard_device(0, 1, strip.data_ptr(), sb, stream=stream.cuda_stream)
