@@ -56,7 +56,8 @@ N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2   # 256 CUs x 4 SIMDs; a wave64 V
 def frame_flops(st, n_lights, n_objs=1) -> float:
     leaf_boxes = max(0, st.box_tests - 4 * st.node_visits)
     shaded = st.rays_shadow / max(1, n_lights)
-    return (NODE_FLOP * st.node_visits + BOX_FLOP * leaf_boxes + TRI_FLOP * st.tri_tests + RAY_FLOP * st.rays() * n_objs +
+    traced = st.rays() - st.rays_shadow_culled   # a culled shadow ray is never started
+    return (NODE_FLOP * st.node_visits + BOX_FLOP * leaf_boxes + TRI_FLOP * st.tri_tests + RAY_FLOP * traced * n_objs +
             shaded * (SETUP_FLOP + HIT_FLOP + LIGHT_FLOP * n_lights))
 
 
@@ -148,13 +149,13 @@ def main():
         stats = [N.Stats()]
         sr.render(stats=stats[-1])
         torch.cuda.synchronize()
-    my_rays = stats[-1].rays()
+    my_rays, my_culled = stats[-1].rays(), stats[-1].rays_shadow_culled
     if distributed:
-        t = torch.tensor([my_rays], dtype=torch.int64, device="cuda")
+        t = torch.tensor([my_rays, my_culled], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        frame_rays = int(t.item())
+        frame_rays, frame_culled = int(t[0].item()), int(t[1].item())
     else:
-        frame_rays = int(my_rays)
+        frame_rays, frame_culled = int(my_rays), int(my_culled)
 
     # ---- untimed for the metric: the same K frames with two in flight (throughput of a frame sequence) -------------
     pipelined = None
@@ -258,7 +259,11 @@ def main():
             "config": {"workload": f"car_objs stand-in (procedural, {scene.triangle_count()} triangles, one object) "
                                    f"{args.width}x{args.height}, {args.spp} spp, max_depth {args.max_depth} "
                                    f"(reflection depth {args.max_depth - 1}), {n_lights} lights, tiles sharded over {world} GPU(s)",
-                       "rays_per_frame": frame_rays, "scene_upload_s": round(upload_s, 2), "bvh_build": args.build,
+                       "rays_per_frame": frame_rays, "shadow_rays_culled_per_frame": frame_culled,
+                       "rays_note": "value counts the reference algorithm's rays (SURVEY.md 8d); shadow_rays_culled of them are "
+                                    "answered without a traversal because their light adds exactly nothing at the hit (DESIGN.md 4)",
+                       "mrays_traced_per_s": round((frame_rays - frame_culled) * args.steps / elapsed / 1e6, 2) if elapsed > 0 else 0.0,
+                       "scene_upload_s": round(upload_s, 2), "bvh_build": args.build,
                        "frames_in_flight": args.frames_in_flight},
             "pipelined": pipelined, "roofline": roofline, "cpu_baseline": cpu,
         }

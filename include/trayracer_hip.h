@@ -130,6 +130,9 @@ typedef struct trr_stats {
     uint64_t trans_lanes;          /* lanes that took part in them */
     uint64_t wave_uniform_node_steps; /* inner-node iterations in which every participating lane stood on the same node */
     uint64_t queue_overflows;      /* pushes beyond a wavefront's ray-queue capacity: always 0 (the capacity is a proven bound) */
+    uint64_t rays_shadow_culled;   /* of rays_shadow: answered without a traversal, because the light's diffuse and specular
+                                    * intensities at the hit are exactly 0.0 and the material is no mirror -- whatever the ray
+                                    * found, mod.rs:171-196 would add exactly nothing */
 } trr_stats;
 
 typedef void (*trr_progress_cb)(void* user, uint32_t blocks_done, uint32_t blocks_total);

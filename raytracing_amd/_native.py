@@ -61,7 +61,8 @@ class Stats(C.Structure):
                 ("trace_launches", C.c_uint32), ("blocks_rendered", C.c_uint32),
                 ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64), ("wave_outer_steps", C.c_uint64),
                 ("wave_lane_steps", C.c_uint64), ("wave_trans_steps", C.c_uint64), ("trans_lanes", C.c_uint64),
-                ("wave_uniform_node_steps", C.c_uint64), ("queue_overflows", C.c_uint64)]
+                ("wave_uniform_node_steps", C.c_uint64), ("queue_overflows", C.c_uint64),
+                ("rays_shadow_culled", C.c_uint64)]
 
     def rays(self) -> int:
         return self.rays_primary + self.rays_shadow + self.rays_reflection + self.rays_march

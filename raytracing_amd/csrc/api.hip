@@ -1002,6 +1002,7 @@ static void finish_stats(trr_ctx* ctx, const trr_ctx::PendingStats& f) {
         stats->rays_shadow += k[KC_SHADOW_RAYS];
         stats->rays_reflection += k[KC_CHAIN_RAYS];
         stats->queue_overflows += k[KC_QUEUE_OVERFLOW];
+        stats->rays_shadow_culled += k[KC_SHADOW_CULLED];
         stats->node_visits += k[KC_NODES]; stats->box_tests += k[KC_BOXES]; stats->tri_tests += k[KC_TRIS]; stats->rays_march += k[KC_MARCH];
         stats->wave_node_steps += k[KC_WNODE]; stats->wave_tri_steps += k[KC_WTRI]; stats->wave_outer_steps += k[KC_WOUTER];
         stats->wave_lane_steps += k[KC_WLANES]; stats->wave_trans_steps += k[KC_WTRANS]; stats->trans_lanes += k[KC_LTRANS];
@@ -1074,6 +1075,7 @@ struct BatchGrids {
     uint32_t chunk_min[2];     // persistent: smallest claim of work items per wavefront in the first / the follow-up launches
     uint32_t raygen, secondary;   // levels: grids of the camera-ray and the secondary-ray launches
     uint32_t levels;              // levels: chain levels that can hold a hit (1 when no material is a mirror, else max_depth)
+    uint32_t cull;                // levels: 1 = k_setup culls the shadow rays of lights that add exactly nothing (kernels.hip)
     uint32_t split;               // levels: 1 = reflection rays and shadow rays in launches of their own, on streams of their own
     uint32_t drain_level;         // levels: from this level's set-up on, ONE k_trace launch (grid `trace`) drains the rest of the
                                   // batch -- the level's shadow rays, the next level's reflection rays and all they spawn
@@ -1103,6 +1105,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
         tio.first_tri = ids_tri_dev;
         tio.counters = kc;
         tio.spill = w.spill;
+        tio.cull = g.cull;
         // Launch 0 takes the camera rays.  With follow-ups, a wavefront that can claim no more work items spills the rays
         // it would queue, and launch k >= 1 deals what launch k - 1 spilled evenly over all wavefronts (the last one spills
         // nothing; a chain is at most max_depth reflection rays long, so deeper follow-ups would find nothing).
@@ -1156,6 +1159,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
                 sio.n_chain_in = cw + CW_NCHAIN + lvl;
                 sio.hits = w.hits; sio.level = w.level; sio.term = w.term; sio.nlev = w.nlev;
                 sio.shadow_compact = compact;
+                sio.occ = w.occ; sio.cull = g.cull;
                 sio.shadow_out = sq;
                 sio.n_shadow_out = cw + CW_NSHADOW + lvl;
                 sio.chain_out = w.chain_q[(lvl + 1) & 1];
@@ -1210,6 +1214,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
             const bool wide_shadow = e_shadow && e_shadow[0] == 'w';
             const uint32_t compact = (!wide_shadow && fp.n_lights <= 128u && bp.cap <= (1u << 25)) ? 1u : 0u;
             sio.shadow_compact = compact;
+            sio.occ = w.occ; sio.cull = g.cull;
             sio.shadow_out = w.shadow_q;
             sio.n_shadow_out = cw + CW_NSHADOW + lvl;
             sio.chain_out = w.chain_q[(lvl + 1) & 1];
@@ -1230,6 +1235,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
                 d.qcap = queue_capacity(fp.n_lights);
                 d.counters = kc;
                 d.spill = w.spill;
+                d.cull = g.cull;
                 d.work_counter = cw + CW_WORK + CW_WORK_STRIDE * (lvl + 1);
                 d.src_q = w.shadow_q; d.src_n = cw + CW_NSHADOW + lvl; d.src_cap = bp.cap * std::max(1u, fp.n_lights);
                 d.src_q2 = w.chain_q[(lvl + 1) & 1]; d.src_n2 = cw + CW_NCHAIN + lvl + 1; d.src_cap2 = bp.cap;
@@ -1402,6 +1408,10 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     // thin deep levels' launch tails cost; one that keeps two frames in flight (TRR_FLAG_PIPELINED) already hides those
     // tails behind the other frame and only pays k_trace's dearer rays (30.6 / 31.3, 12.3 / 13.4), so it keeps the levels.
     grids.levels = sc->any_reflective ? max_depth : std::min(max_depth, 1u);
+    {
+        const char* ce = std::getenv("TRR_CULL");
+        grids.cull = (ce && ce[0] == '0') ? 0u : 1u;
+    }
     // Split schedule (queue_batch): every level's shadow rays on a stream of their own, off the chain of reflection rays.  It
     // needs more concurrent streams than HIP's default of 4 hardware queues carries -- with 4, streams of different lanes
     // share a queue and whole batches serialise (an eighth of the 4K x 16 spp frame 5.7 instead of 5.4 ms) -- so it is
@@ -1703,6 +1713,10 @@ int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, ui
     grids.followups = 0;
     grids.drain_level = NO_DRAIN;   // (the drain's ray queues would take scratch from the batch)
     grids.levels = sc->any_reflective ? max_depth : std::min(max_depth, 1u);
+    {
+        const char* ce = std::getenv("TRR_CULL");
+        grids.cull = (ce && ce[0] == '0') ? 0u : 1u;
+    }
     grids.chunk_min[0] = 64; grids.chunk_min[1] = 16;
     const uint32_t spill_grid = schedule == SCHED_PERSISTENT ? grids.trace : grids.raygen;
     // the largest whole number of blocks per batch whose work set fits the scratch array
@@ -2053,6 +2067,7 @@ static int multi_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t ma
             sum.blocks_rendered += a.blocks_rendered; sum.wave_node_steps += a.wave_node_steps; sum.wave_tri_steps += a.wave_tri_steps;
             sum.wave_outer_steps += a.wave_outer_steps; sum.wave_lane_steps += a.wave_lane_steps; sum.wave_trans_steps += a.wave_trans_steps;
             sum.trans_lanes += a.trans_lanes; sum.wave_uniform_node_steps += a.wave_uniform_node_steps; sum.queue_overflows += a.queue_overflows;
+            sum.rays_shadow_culled += a.rays_shadow_culled;
         }
         sum.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
         *stats_out = sum;

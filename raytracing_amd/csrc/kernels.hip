@@ -250,6 +250,8 @@ DEV bool candidate_better(bool have, float key, uint32_t tri, float best_key, ui
 constexpr uint32_t META_SHADOW = 0x100u;
 constexpr uint32_t COMPACT_MAX_LIGHTS = 128u, COMPACT_SAMPLE_BITS = 25u;
 constexpr uint32_t TRI_FLAG_TRANSPARENT = 1u, TRI_FLAG_REFLECTIVE = 2u;   // TriRec.flags
+// occluder codes of a (level, light, sample): a material id, -1 nothing hit, -2 a hit without material, and
+constexpr int32_t OCC_CULLED = -3;   // no shadow ray traced: the light adds exactly nothing at this hit (k_setup)
 constexpr uint8_t NLEV_PENDING = 0xFF;   // nlev of a camera sample whose hit waits for k_setup (max_depth <= 254 keeps it free)
 constexpr uint32_t MARCH_CAP = 0xFFFFu;   // raycasts of one transparency march (mod.rs:100-111); the reference has no cap and
                                           // would spin for ever on a ray that cannot advance (zero / NaN direction) -- the
@@ -384,7 +386,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
     int sp = 0;
     unsigned long long c_nodes = 0, c_boxes = 0, c_tris = 0, c_march = 0;
     unsigned long long c_wnode = 0, c_wtri = 0, c_wouter = 0, c_lanes = 0, c_wtrans = 0, c_ltrans = 0, c_wuni = 0;   // wave-level step counts (SIMD efficiency)
-    uint32_t n_pushed_shadow = 0, n_pushed_chain = 0, n_overflow = 0;   // wave-uniform
+    uint32_t n_pushed_shadow = 0, n_pushed_chain = 0, n_overflow = 0, n_culled = 0;   // wave-uniform
 
     auto push = [&](uint32_t ref, float tmin) {
         uint2 e = make_uint2(ref, __float_as_uint(tmin));
@@ -725,7 +727,40 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
                 }
                 const unsigned long long sm = __ballot(spawn);
                 const uint32_t nh = (uint32_t)__popcll(hm), ns = (uint32_t)__popcll(sm);
-                const uint32_t need = nh * L + ns;
+                // shadow-ray cull (see k_setup): lights whose two intensities are exactly 0.0 at a non-reflective hit
+                const bool do_cull = io.cull != 0u && L <= 64u;
+                unsigned long long keep = 0ull;   // per lane: bit l = light l's shadow ray is traced
+                uint32_t n_kept = nh * L;
+                if (do_cull) {
+                    if (final_hit) {
+                        bool specular = false;
+                        float ns_exp = 1.0f;
+                        if (h_mat >= 0) {
+                            const MatRec* m = fp.mats + h_mat;
+                            if (m->flags & 4u) ns_exp = m->ns;
+                            specular = (m->illum == 2);
+                        }
+                        const bool reflective = (h_flags & TRI_FLAG_REFLECTIVE) != 0u;
+                        const F3 rv = reflect(neg(rd), N);
+                        for (uint32_t l = 0; l < L; ++l) {
+                            const LightRec* lt = fp.lights + l;
+                            const F3 lp = f3(lt->pos[0], lt->pos[1], lt->pos[2]);
+                            const F3 ld = normalize(lp - P);
+                            const float li = lt->intensity / norm_squared(lp - P);
+                            const float di = rmax(dot(ld, N), 0.0f) * li;
+                            bool dark = !reflective && di == 0.0f;
+                            if (dark && specular) {
+                                const float sint = powf(rmax(dot(ld, rv), 0.0f), ns_exp) * li;
+                                dark = sint == 0.0f;
+                            }
+                            if (dark) io.occ[((size_t)level * L + l) * cap + r_sample] = OCC_CULLED;
+                            else keep |= 1ull << l;
+                        }
+                    }
+                    n_kept = 0;
+                    for (uint32_t l = 0; l < L; ++l) n_kept += (uint32_t)__popcll(__ballot((keep >> l) & 1ull));
+                }
+                const uint32_t need = n_kept + ns;
                 // destination: the wavefront's own ring, or -- once it can claim no more work items -- the spill queue of
                 // the launch (one returning atomic per wavefront and set-up)
                 const bool spill = exhausted && io.spill_q != nullptr;
@@ -744,7 +779,22 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
                     q_tail += need;
                 }
                 if (!room) n_overflow++;   // cannot happen (capacities are proven bounds, see api.hip); counted, never out of bounds
-                if (final_hit && room) {
+                if (do_cull && room) {
+                    uint32_t off = 0;
+                    for (uint32_t l = 0; l < L; ++l) {
+                        const bool mine = ((keep >> l) & 1ull) != 0ull;
+                        const unsigned long long km = __ballot(mine);
+                        if (mine) {
+                            const LightRec* lt = fp.lights + l;
+                            const F3 ld = normalize(f3(lt->pos[0], lt->pos[1], lt->pos[2]) - P);   // mod.rs:149
+                            const F3 o = P + scale(ld, delta);                                     // mod.rs:151
+                            float4* e = dst + (size_t)((base + off + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))) & mask) * 2u;
+                            e[0] = make_float4(o.x, o.y, o.z, ld.x);
+                            e[1] = make_float4(ld.y, ld.z, __uint_as_float(r_sample), __uint_as_float(level | META_SHADOW | (l << 16)));
+                        }
+                        off += (uint32_t)__popcll(km);
+                    }
+                } else if (final_hit && room) {
                     // shadow rays: mod.rs:149-153, one per light, grouped per light (coherent re-fills)
                     const uint32_t rk = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
                     for (uint32_t l = 0; l < L; ++l) {
@@ -760,11 +810,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
                     // reflection ray: mod.rs:203-206 (traced once per hit; the value is light-independent)
                     const uint32_t rk = (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
                     const F3 o = P + scale(N, delta), d = reflect(rd, N);
-                    float4* e = dst + (size_t)((base + nh * L + rk) & mask) * 2u;
+                    float4* e = dst + (size_t)((base + n_kept + rk) & mask) * 2u;
                     e[0] = make_float4(o.x, o.y, o.z, d.x);
                     e[1] = make_float4(d.y, d.z, __uint_as_float(r_sample), __uint_as_float(level + 1u));
                 }
                 n_pushed_shadow += nh * L;
+                n_culled += nh * L - n_kept;
                 n_pushed_chain += ns;
             }
         }
@@ -782,6 +833,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
         atomicAdd(io.counters + 11, (unsigned long long)n_pushed_shadow);
         atomicAdd(io.counters + 12, (unsigned long long)n_pushed_chain);
         if (n_overflow) atomicAdd(io.counters + 13, (unsigned long long)n_overflow);
+        if (n_culled) atomicAdd(io.counters + KC_SHADOW_CULLED, (unsigned long long)n_culled);
     }
     if (COUNT) {
         // wave reduction, then one atomic per wavefront and counter
@@ -1118,13 +1170,15 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
     // whole wavefronts iterate together (the ballots below need every lane present)
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounds = (total + stride - 1) / stride;
-    uint32_t n_sh = 0, n_ch = 0;   // wave-uniform: rays queued by this wavefront
+    uint32_t n_sh = 0, n_ch = 0, n_cull = 0;   // wave-uniform: rays queued by this wavefront (n_sh includes the n_cull culled ones)
     for (uint32_t it = 0; it < rounds; ++it) {
         uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         bool valid = i < total;
         bool hit = false, spawn = false;
         F3 P = f3(0, 0, 0), N = f3(0, 0, 0), D = f3(0, 0, 0);
         uint32_t sample = 0;
+        int32_t hit_mat = -1;
+        bool hit_reflective = false;
         if (LEVEL0 && valid && io.nlev[i] != NLEV_PENDING) valid = false;   // a camera ray that missed: nothing to set up
         if (valid) {
             if (LEVEL0) {
@@ -1172,6 +1226,8 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
                 P = xform_point(ob->fwd, point);
                 N = xform_vec(ob->fwd, normal);
                 const bool reflective = (__float_as_uint(h1.w) & TRI_FLAG_REFLECTIVE) != 0u;   // material.rs:47-49
+                hit_mat = __float_as_int(h1.z);
+                hit_reflective = reflective;
                 float4* lv = io.level + ((size_t)lvl * cap + sample) * LEVEL_F4;
                 lv[0] = make_float4(P.x, P.y, P.z, N.x);
                 lv[1] = make_float4(N.y, N.z, D.x, D.y);
@@ -1189,7 +1245,67 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
         }
         // ---- shadow rays: mod.rs:149-153, one per light, grouped per light inside the wavefront's chunk ----
         unsigned long long hm = __ballot(hit);
-        if (hm != 0ull && L > 0) {
+        if (hm != 0ull && L > 0 && io.cull != 0u && L <= 64u) {
+            // Shadow-ray cull.  A light whose diffuse AND specular intensities (mod.rs:176-177, 184-195) are exactly 0.0
+            // adds exactly nothing to the colour whatever its shadow ray finds (mod.rs:171-173 skips it, or :178 / :196
+            // add a colour times 0.0), unless the material is reflective (the `continue` of :171-173 would also skip the
+            // reflection term, :207) -- so that ray is not traced: the pair's occluder code says OCC_CULLED and the
+            // resolve pass skips the light.  The two intensities are evaluated here with the resolve pass's own
+            // operations; 0.0 * li is 0.0 only for a finite li, NaN otherwise (then the ray is traced).
+            unsigned long long keep = 0ull;   // per lane: bit l = light l's shadow ray is traced
+            if (hit) {
+                bool specular = false;
+                float ns = 1.0f;
+                if (hit_mat >= 0) {
+                    const MatRec* m = fp.mats + hit_mat;
+                    if (m->flags & 4u) ns = m->ns;
+                    specular = (m->illum == 2);
+                }
+                const bool reflective = hit_reflective;
+                const F3 rv = reflect(neg(D), N);
+                for (uint32_t l = 0; l < L; ++l) {
+                    const LightRec* lt = fp.lights + l;
+                    const F3 lp = f3(lt->pos[0], lt->pos[1], lt->pos[2]);
+                    const F3 ld = normalize(lp - P);
+                    const float li = lt->intensity / norm_squared(lp - P);
+                    const float di = rmax(dot(ld, N), 0.0f) * li;
+                    bool dark = !reflective && di == 0.0f;
+                    if (dark && specular) {
+                        const float sint = powf(rmax(dot(ld, rv), 0.0f), ns) * li;
+                        dark = sint == 0.0f;
+                    }
+                    if (dark) io.occ[((size_t)lvl * L + l) * cap + sample] = OCC_CULLED;
+                    else keep |= 1ull << l;
+                }
+            }
+            uint32_t total_rays = 0;
+            for (uint32_t l = 0; l < L; ++l) total_rays += (uint32_t)__popcll(__ballot((keep >> l) & 1ull));
+            n_sh += (uint32_t)__popcll(hm) * L;   // the statistics count the algorithm's rays, traced or culled
+            n_cull += (uint32_t)__popcll(hm) * L - total_rays;
+            uint32_t base = 0;
+            if (total_rays != 0u) {
+                if (lane == 0) base = atomicAdd(io.n_shadow_out, total_rays);
+                base = __shfl(base, 0);
+            }
+            for (uint32_t l = 0; l < L && total_rays != 0u; ++l) {
+                const bool mine = ((keep >> l) & 1ull) != 0ull;
+                const unsigned long long km = __ballot(mine);
+                const uint32_t rank = (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                if (mine) {
+                    if (io.shadow_compact != 0u) {
+                        io.shadow_out[base + rank] = make_float4(P.x, P.y, P.z, __uint_as_float(sample | (l << COMPACT_SAMPLE_BITS)));
+                    } else {
+                        const LightRec* lt = fp.lights + l;
+                        F3 ld = normalize(f3(lt->pos[0], lt->pos[1], lt->pos[2]) - P);   // mod.rs:149
+                        F3 o = P + scale(ld, fp.delta);                                  // mod.rs:151
+                        float4* e = io.shadow_out + (size_t)(base + rank) * 2u;
+                        e[0] = make_float4(o.x, o.y, o.z, ld.x);
+                        e[1] = make_float4(ld.y, ld.z, __uint_as_float(sample), __uint_as_float(lvl | META_SHADOW | (l << 16)));
+                    }
+                }
+                base += (uint32_t)__popcll(km);
+            }
+        } else if (hm != 0ull && L > 0) {
             uint32_t nh = (uint32_t)__popcll(hm);
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(io.n_shadow_out, nh * L);
@@ -1231,6 +1347,7 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
     if (lane == 0 && (n_sh | n_ch) != 0u) {   // the ray statistics of trr_stats
         atomicAdd(io.counters + KC_SHADOW_RAYS, (unsigned long long)n_sh);
         atomicAdd(io.counters + KC_CHAIN_RAYS, (unsigned long long)n_ch);
+        if (n_cull != 0u) atomicAdd(io.counters + KC_SHADOW_CULLED, (unsigned long long)n_cull);
     }
 }
 
@@ -1302,6 +1419,7 @@ DEV F3 resolve_sample(const FrameParams& fp, const BatchParams& bp, const Resolv
                 F3 lp = f3(lt->pos[0], lt->pos[1], lt->pos[2]);
                 F3 ld = normalize(lp - P);   // mod.rs:149
                 int32_t oc = io.occ[((size_t)k * L + l) * cap + s];
+                if (oc == OCC_CULLED) continue;   // k_setup found both intensities of this light exactly 0.0: it adds nothing
                 F3 trans;
                 if (oc == -1) trans = f3(1.0f, 1.0f, 1.0f);   // mod.rs:160
                 else {

@@ -27,6 +27,7 @@ struct TraceIO {
     uint32_t* spill_n;
     uint32_t spill_cap;
     uint32_t chunk_min;           // smallest claim of work items per wavefront (>= 1)
+    uint32_t cull;                // 1: no shadow ray for a light that adds exactly nothing at a hit (kernels.hip: k_setup)
     uint32_t* first_obj;          // nullable: id buffers of the camera rays' first closest hits
     uint32_t* first_tri;
     unsigned long long* counters; // kernel counters (device_types.h: KC_*)
@@ -59,6 +60,8 @@ struct SetupIO {
     float4* shadow_out;
     uint32_t* n_shadow_out;
     uint32_t shadow_compact;      // 1: write 16-B compact shadow entries
+    int32_t* occ;                 // occluder codes; a culled (hit, light) pair gets OCC_CULLED here instead of a shadow ray
+    uint32_t cull;                // 1: cull shadow rays whose light contributes exactly nothing (kernels.hip)
     float4* chain_out;
     uint32_t* n_chain_out;
     unsigned long long* counters;

@@ -22,6 +22,7 @@ ENVS = [
     {"TRR_SCHEDULE": "levels", "TRR_DRAIN_LEVEL": "1"}, {"TRR_SCHEDULE": "levels", "TRR_SHADOW": "wide"},
     {"TRR_SCHEDULE": "levels", "TRR_NODES": "quantised"}, {"TRR_SCHEDULE": "levels", "TRR_BATCHES": "3"},
     {"TRR_SCHEDULE": "levels", "TRR_RESOLVE": "two_pass"}, {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1"},
+    {"TRR_SCHEDULE": "levels", "TRR_CULL": "0"}, {"TRR_SCHEDULE": "persistent", "TRR_CULL": "0"},
     {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "0", "TRR_DRAIN_LEVEL": "1"}, {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1", "TRR_SHADOW": "wide"},
 ]
 KEYS = sorted({k for e in ENVS for k in e})

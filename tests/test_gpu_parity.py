@@ -227,10 +227,19 @@ def test_update_camera_lights_instances_between_renders(ctx, oracle_mod):
     assert not np.array_equal(a["rgb"], b["rgb"])
 
 
-def test_stats_ray_accounting_matches_oracle(ctx, oracle_mod):
+def test_stats_ray_accounting_matches_oracle(ctx, oracle_mod, monkeypatch):
     sc = standin.parity_scene(96, 72, detail=6)
+    culled = gpu_render(ctx, sc, max_depth=4, counters=True)
+    monkeypatch.setenv("TRR_CULL", "0")   # every shadow ray traced, as the oracle does
     out = gpu_render(ctx, sc, max_depth=4, counters=True)
-    st = out["stats"]
+    monkeypatch.delenv("TRR_CULL")
+    st, sc_ = out["stats"], culled["stats"]
+    # the shadow-ray cull changes no pixel and no count of the algorithm's rays; what it saves shows in
+    # rays_shadow_culled, in the traversal counters and in the march queries the culled rays would have made
+    assert np.array_equal(culled["rgb"], out["rgb"]) and np.array_equal(culled["hit_tri"], out["hit_tri"])
+    assert (sc_.rays_primary, sc_.rays_shadow, sc_.rays_reflection) == (st.rays_primary, st.rays_shadow, st.rays_reflection)
+    assert st.rays_shadow_culled == 0 and 0 < sc_.rays_shadow_culled < sc_.rays_shadow
+    assert sc_.rays_march <= st.rays_march and sc_.node_visits < st.node_visits
     ref = oracle_mod.OracleScene(sc).render(shade=oracle_mod.SHADE_HOISTED, max_depth=4, want_ids=False)
     # The hoisted oracle makes nearly the de-duplicated closest-hit queries we count.  Two known differences, both
     # result-neutral: it still casts the reflection ray of the deepest level (whose value is skybox(direction) hit or
