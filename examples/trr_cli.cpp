@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
             std::fwrite(im.rgb.data(), 1, im.rgb.size(), f);
             std::fclose(f);
             return 0;
-        } catch (const loader::LoadError& e) {
+        } catch (const std::exception& e) {   // LoadError, and anything else a hostile file can raise
             std::fprintf(stderr, "error: %s\n", e.what());
             return 2;
         }

@@ -38,6 +38,13 @@ struct Rgb8 {
 struct DecodeError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
+// A header may claim any size (65535 x 65535 JPEG, 2^31 x 2^31 EXR): refuse what no texture or sky of this renderer is --
+// above 2^28 pixels (16384 x 16384; the reference's largest sky is 8192 x 4096) -- before anything is allocated for it.
+constexpr uint64_t MAX_PIXELS = 1ull << 28;
+inline void check_dimensions(uint64_t w, uint64_t h) {
+    if (w == 0 || h == 0 || w > (1ull << 20) || h > (1ull << 20) || w * h > MAX_PIXELS)
+        throw DecodeError("image dimensions " + std::to_string(w) + " x " + std::to_string(h) + " out of range");
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // TIFF
@@ -191,6 +198,7 @@ inline Rgb8 decode(const std::string& d) {
     rows_per_strip = std::min(rows_per_strip, height);
     const size_t row_bytes = (size_t)width * spp;
 
+    check_dimensions(width, height);
     Rgb8 im;
     im.width = width; im.height = height;
     im.rgb.resize((size_t)width * height * 3);
@@ -409,6 +417,7 @@ inline Rgb8 decode(const std::string& d) {
             width = (s[3] << 8) | s[4];
             const int nc = s[5];
             if (width <= 0 || height <= 0 || (nc != 1 && nc != 3) || sl < 6 + 3 * nc) throw DecodeError("unsupported JPEG frame");
+            check_dimensions((uint64_t)width, (uint64_t)height);
             comps.assign((size_t)nc, Component());
             for (int c = 0; c < nc; ++c) {
                 comps[c].id = s[6 + 3 * c];
@@ -434,6 +443,8 @@ inline Rgb8 decode(const std::string& d) {
                 for (auto& c : comps)
                     if (c.id == cid) { c.td = s[2 + 2 * k] >> 4; c.ta = s[2 + 2 * k] & 15; found = true; }
                 if (!found) throw DecodeError("JPEG scan names an unknown component");
+                // Td / Ta index dc[4] / ac[4] below: a baseline scan may only name tables 0..3 (T.81 B.2.3)
+                if ((s[2 + 2 * k] >> 4) > 3 || (s[2 + 2 * k] & 15) > 3) throw DecodeError("bad JPEG table selector");
             }
             pos += (size_t)len;
             break;
@@ -715,6 +726,10 @@ inline void huf_uncompress(const uint8_t* src, size_t n, uint16_t* out, size_t n
     for (uint32_t i = im; i <= iM; ++i) count[len[i]]++;
     uint64_t c = 0;
     for (int l = 58; l > 0; --l) { const uint64_t nc = (c + count[l]) >> 1; start[l] = c; c = nc; }
+    // an over-subscribed table (Kraft sum above 1, e.g. three symbols of length 1) would give codes of length l that do not
+    // fit l bits: refuse it here, before the codes index the look-up table below
+    for (int l = 1; l <= 58; ++l)
+        if (count[l] && start[l] + count[l] > (1ull << l)) throw DecodeError("corrupt EXR PIZ code table (over-subscribed)");
     std::vector<uint32_t> first(60, 0), syms;
     syms.reserve(iM - im + 1);
     for (int l = 1; l <= 58; ++l) {
@@ -729,6 +744,7 @@ inline void huf_uncompress(const uint8_t* src, size_t n, uint16_t* out, size_t n
             const uint64_t code = start[l] + k;
             const uint32_t s = syms[first[l] + (uint32_t)k];
             const uint32_t base = (uint32_t)(code << (FAST - l));
+            if ((size_t)base + (1u << (FAST - l)) > fast.size()) throw DecodeError("corrupt EXR PIZ code table");
             for (uint32_t f = 0; f < (1u << (FAST - l)); ++f) fast[base + f] = (s << 6) | (uint32_t)l;
         }
     const uint8_t* data = src + 20 + used;
@@ -976,6 +992,7 @@ inline Rgb8 decode(const std::string& d) {
     size_t px_bytes = 0;   // bytes of one pixel over all channels
     std::vector<size_t> ch_off(ch.size());
     for (size_t c = 0; c < ch.size(); ++c) px_bytes += ch[c].bytes();
+    check_dimensions((uint64_t)W, (uint64_t)H);
     Rgb8 im;
     im.width = (uint32_t)W; im.height = (uint32_t)H;
     im.rgb.assign((size_t)W * H * 3, 0);

@@ -17,8 +17,9 @@
 // plain / quoted scalars, comments, the tags !Color / !Path; no anchors, no multi-line scalars.
 // Images: 8-bit non-interlaced PNG (all colour types) and binary PPM decode here, TIFF (strips, 8-bit; none / LZW /
 // PackBits) and baseline JPEG in trayracer_image.hpp -- the formats of the reference's own test textures
-// (res/test/textures/).  OpenEXR does not decode (the reference's EXR skyboxes are git-LFS stubs: nothing to pin a decoder
-// against).  A texture that fails to load only warns (object.rs:92-96); a skybox that fails makes extraArgs fall back to
+// (res/test/textures/) -- and OpenEXR (scan-line and one-level tiled; NONE / RLE / ZIPS / ZIP / PIZ / PXR24), the format
+// of the reference's skyboxes, PARITY UNPINNED: those files are git-LFS stubs, so the decoder is checked against our own
+// encoder only (tests/test_exr_decode.py).  A texture that fails to load only warns (object.rs:92-96); a skybox that fails makes extraArgs fall back to
 // the defaults (mod.rs:100-110).
 #pragma once
 
@@ -188,6 +189,8 @@ inline Image load_image_rgb8(const std::string& path) {
     } catch (const LoadError& e) {
         throw LoadError("Failed to load image from path: " + path + ": " + e.what());
     } catch (const imgdec::DecodeError& e) {
+        throw LoadError("Failed to load image from path: " + path + ": " + e.what());
+    } catch (const std::exception& e) {   // bad_alloc / length_error from a hostile header: a failed image::open, not a crash
         throw LoadError("Failed to load image from path: " + path + ": " + e.what());
     }
 }

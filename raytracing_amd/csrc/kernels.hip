@@ -178,6 +178,10 @@ constexpr int STACK_SPILL = TRACE_STACK_ENTRIES - STACK_LDS;     // further entr
 #define TRR_REFILL_MIN 42   // swept 24..48 with TRR_DEFER_END: 31.4 / 30.9 / 30.6 (36) / 30.25 (42) / 30.5 ms
 #endif
 constexpr int REFILL_MIN = TRR_REFILL_MIN;      // re-fill when at least this many of the 64 lanes are idle
+#ifndef TRR_END_MIN
+#define TRR_END_MIN 16
+#endif
+constexpr int END_MIN = TRR_END_MIN;            // staged ray starts (k_trace_level<.., ST>): ray ends run once this many lanes wait
 #ifndef TRR_PRUNE_REL
 #define TRR_PRUNE_REL 1.0e-3f
 #endif
@@ -874,9 +878,18 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
 // Every wavefront does one thing (thin ray start / end blocks, hit set-up with full wavefronts), which makes a ray cheaper
 // than in k_trace; the price is 2 * max_depth + 1 dependent launches per batch, each with a ramp-up and a tail.
 // ------------------------------------------------------------------------------------------------
-template <bool RAYGEN, bool COUNT, bool QN>
+// ST ("staged ray starts", secondary-ray launches only): a wavefront turns its next 64 queue entries into started rays with
+// ALL 64 lanes at once -- the ray of mod.rs:149-153 / 203-206, its direction in object 0's space, the norm and the six
+// divisions of bvh::Ray::new (object.rs:186-195) -- and parks them in LDS (48 B per ray); a lane whose ray has ended then
+// STARTS its next ray with three LDS reads and the two matrix products, no division, no square root, no memory round trip.
+// The arithmetic of a ray is the same as in the transition block below (same functions, same operands), so the same bits.
+// What it buys: ray ends no longer have to wait for 42 lanes of company to make the long start block worth its while
+// (END_MIN instead of REFILL_MIN): finished lanes were 25 % of all lane-steps of the 4K x 16 spp frame.
+template <bool RAYGEN, bool COUNT, bool QN, bool ST>
 __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_level(FrameParams fp, BatchParams bp, LevelIO io) {
+    static_assert(!(RAYGEN && ST), "staged ray starts are for the secondary-ray launches");
     __shared__ uint2 s_stack[STACK_LDS * TRACE_THREADS];
+    __shared__ float4 s_stage[ST ? 3 * TRACE_THREADS : 1];   // [3][wavefronts of the block][64 slots]
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     uint2* my_spill = io.spill + ((size_t)blockIdx.x * TRACE_THREADS + tid) * STACK_SPILL;
@@ -945,10 +958,91 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
         return REF_EMPTY;
     };
 
+    // ST: object 0, where every ray starts (wave-uniform); the staging slots of this wavefront
+    uint32_t root0 = REF_EMPTY, skip0 = 0u;
+    float slack0 = 0.0f;
+    if (ST) {
+        root0 = fp.objs[0].root;
+        skip0 = (fp.objs[0].flags & 1u) ? F_SKIPBOX : 0u;
+        slack0 = fp.objs[0].slack_abs;
+    }
+    float4* const my_stage = s_stage + (ST ? (tid & ~63u) : 0u);
+    uint32_t stage_head = 0, stage_n = 0;   // wave-uniform: staged rays not yet handed to a lane
+
     for (;;) {
         // ---- re-fill idle lanes -------------------------------------------------------------
         unsigned long long idle = __ballot(cur == REF_IDLE);
-        if (idle != 0ull && !exhausted) {
+        if (ST && idle != 0ull) {
+            if (stage_n == 0u && !exhausted) {
+                // stage the wavefront's next (up to) 64 work items, one per lane, busy lanes included
+                if (w_next >= w_end && !work_claim_next(claim, io.work_counter, total, lane, w_next, w_end)) {
+                    exhausted = true;
+                    w_next = w_end = 0;
+                }
+                const uint32_t n = min(64u, w_end - w_next);
+                if (lane < n) {
+                    const uint32_t idx = w_next + lane;
+                    F3 o, d;
+                    uint32_t rid, meta;
+                    if (io.shadow_compact != 0u && idx < n_shadow) {
+                        // compact shadow entry: the ray of mod.rs:149-153 from the shaded point, same operations as k_setup's
+                        const float4 a = io.shadow_q[idx];
+                        const uint32_t wd = __float_as_uint(a.w), l = wd >> COMPACT_SAMPLE_BITS;
+                        const F3 P = f3(a.x, a.y, a.z);
+                        const F3 ld = normalize(f3(s_light_pos[3u * l], s_light_pos[3u * l + 1u], s_light_pos[3u * l + 2u]) - P);   // mod.rs:149
+                        o = P + scale(ld, fp.delta);                                                                             // mod.rs:151
+                        d = ld;
+                        rid = wd & ((1u << COMPACT_SAMPLE_BITS) - 1u);
+                        meta = io.shadow_level | META_SHADOW | (l << 16);
+                    } else {
+                        const float4* q = (idx < n_shadow) ? (io.shadow_q + (size_t)idx * 2u) : (io.chain_q + (size_t)(idx - n_shadow) * 2u);
+                        const float4 a = q[0], b = q[1];
+                        o = f3(a.x, a.y, a.z);
+                        d = f3(a.w, b.x, b.y);
+                        meta = __float_as_uint(b.w);
+                        // a shadow ray is known by its sample, a chain ray by its queue position (its hit record's index)
+                        rid = (meta & META_SHADOW) ? __float_as_uint(b.z) : idx - n_shadow;
+                    }
+                    // object.rs:186-195 for object 0: bvh::Ray::new normalises its own copy and keeps 1/direction [crate]
+                    const F3 od0 = xform_vec(fp.objs[0].inv, d);
+                    const float ld0 = norm(od0);
+                    const F3 dn = unscale(od0, ld0);
+                    my_stage[lane] = make_float4(o.x, o.y, o.z, d.x);
+                    my_stage[TRACE_THREADS + lane] = make_float4(d.y, d.z, 1.0f / dn.x, 1.0f / dn.y);
+                    my_stage[2 * TRACE_THREADS + lane] = make_float4(1.0f / dn.z, ld0, __uint_as_float(rid), __uint_as_float(meta));
+                }
+                w_next += n;
+                stage_head = 0;
+                stage_n = n;
+            }
+            if (stage_n != 0u) {
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t take = min((uint32_t)__popcll(idle), stage_n);
+                if (cur == REF_IDLE && rank < take) {
+                    const uint32_t slot = stage_head + rank;
+                    const float4 a = my_stage[slot], b = my_stage[TRACE_THREADS + slot], c = my_stage[2 * TRACE_THREADS + slot];
+                    ro = f3(a.x, a.y, a.z);
+                    rd = f3(a.w, b.x, b.y);
+                    oi = f3(b.z, b.w, c.x);
+                    len_d = c.y;
+                    r_meta = __float_as_uint(c.w);
+                    r_sample = r_out = __float_as_uint(c.z);
+                    oo = xform_point(fp.objs[0].inv, ro);   // object.rs:187
+                    od = xform_vec(fp.objs[0].inv, rd);     // object.rs:188
+                    slack_abs = slack0;
+                    t_lim = INFINITY;
+                    lim_n = INFINITY;   // = t_lim * len_d + slack_abs, or its NaN fallback (the transition block's rule)
+                    if (QN) e_ray = 0x1p-20f * rmax(rmax(fabsf(oo.x), fabsf(oo.y)), fabsf(oo.z)) + 0x1p-6f * slack_abs;
+                    fl = F_FIRST | skip0;
+                    obj_i = 0;
+                    cur = root0;
+                    sp = 0;
+                }
+                stage_head += take;
+                stage_n -= take;
+            }
+        }
+        if (!ST && idle != 0ull && !exhausted) {
             int nidle = __popcll(idle);
             if (nidle >= REFILL_MIN) {
                 if (w_next >= w_end && !work_claim_next(claim, io.work_counter, total, lane, w_next, w_end)) {
@@ -1000,6 +1094,9 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
         if (COUNT) {
             if (lane == 0) c_wouter++;
             if (cur != REF_IDLE) c_lanes++;
+#ifdef TRR_COUNT_WAIT
+            if (cur == REF_EMPTY) c_wuni++;   // experiment: lanes whose traversal has ended and that wait for the transition block
+#endif
         }
 
         // ---- transition: object finished / raycast finished / ray finished (deferred ends: see k_trace) ------------------
@@ -1014,7 +1111,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
             const unsigned long long m_empty = __ballot(is_empty);
             const unsigned long long m_wait = __ballot(can_wait);
             const unsigned long long m_work = __ballot(cur < REF_IDLE);
-            run_trans = m_empty != m_wait || m_work == 0ull || __popcll(m_wait) + __popcll(__ballot(cur == REF_IDLE)) >= REFILL_MIN;
+            run_trans = m_empty != m_wait || m_work == 0ull || __popcll(m_wait) + __popcll(__ballot(cur == REF_IDLE)) >= (ST ? END_MIN : REFILL_MIN);
         }
         if (COUNT && run_trans) {
             unsigned long long tm = __ballot(cur == REF_EMPTY);
@@ -1648,38 +1745,46 @@ void launch_trace(bool count, uint32_t grid, hipStream_t st, const FrameParams& 
     else hipLaunchKernelGGL((k_trace<false>), g, b, 0, st, a);
 }
 
-// the level kernels read the 64-B quantised nodes when the frame has them (fp.qnodes), the exact ones otherwise
-template <bool QN>
-static int level_blocks_per_cu_t(bool raygen, bool count) {
+// the level kernels read the 64-B quantised nodes when the frame has them (fp.qnodes), the exact ones otherwise; the
+// secondary-ray launches use the staged ray starts unless TRR_STAGE=0 (experiments, tests of the older path)
+static bool staged_starts() {
+    static const bool on = [] { const char* e = std::getenv("TRR_STAGE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+template <bool RAYGEN, bool COUNT, bool QN, bool ST>
+static int level_bpc_one() {
     int nb = 0;
-    hipError_t e;
-    if (raygen) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<true, true, QN>, TRACE_THREADS, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<true, false, QN>, TRACE_THREADS, 0);
-    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<false, true, QN>, TRACE_THREADS, 0)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<false, false, QN>, TRACE_THREADS, 0);
-    if (e != hipSuccess || nb < 1) nb = 1;
-    return nb;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<RAYGEN, COUNT, QN, ST>, TRACE_THREADS, 0);
+    return (e != hipSuccess || nb < 1) ? 1 : nb;
 }
 int level_blocks_per_cu(bool raygen, bool count) {
-    return std::min(level_blocks_per_cu_t<false>(raygen, count), level_blocks_per_cu_t<true>(raygen, count));
+    if (raygen) return count ? std::min(level_bpc_one<true, true, false, false>(), level_bpc_one<true, true, true, false>())
+                             : std::min(level_bpc_one<true, false, false, false>(), level_bpc_one<true, false, true, false>());
+    if (staged_starts()) return count ? std::min(level_bpc_one<false, true, false, true>(), level_bpc_one<false, true, true, true>())
+                                      : std::min(level_bpc_one<false, false, false, true>(), level_bpc_one<false, false, true, true>());
+    return count ? std::min(level_bpc_one<false, true, false, false>(), level_bpc_one<false, true, true, false>())
+                 : std::min(level_bpc_one<false, false, false, false>(), level_bpc_one<false, false, true, false>());
 }
 
-template <bool QN>
-static void launch_trace_level_t(bool raygen, bool count, dim3 g, dim3 b, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
-                                 const LevelIO& io) {
-    if (raygen) {
-        if (count) hipLaunchKernelGGL((k_trace_level<true, true, QN>), g, b, 0, st, fp, bp, io);
-        else hipLaunchKernelGGL((k_trace_level<true, false, QN>), g, b, 0, st, fp, bp, io);
-    } else {
-        if (count) hipLaunchKernelGGL((k_trace_level<false, true, QN>), g, b, 0, st, fp, bp, io);
-        else hipLaunchKernelGGL((k_trace_level<false, false, QN>), g, b, 0, st, fp, bp, io);
-    }
+template <bool RAYGEN, bool QN, bool ST>
+static void launch_trace_level_t(bool count, dim3 g, dim3 b, hipStream_t st, const FrameParams& fp, const BatchParams& bp, const LevelIO& io) {
+    if (count) hipLaunchKernelGGL((k_trace_level<RAYGEN, true, QN, ST>), g, b, 0, st, fp, bp, io);
+    else hipLaunchKernelGGL((k_trace_level<RAYGEN, false, QN, ST>), g, b, 0, st, fp, bp, io);
 }
 void launch_trace_level(bool raygen, bool count, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
                         const LevelIO& io) {
     dim3 g(grid), b(TRACE_THREADS);
-    if (fp.qnodes != nullptr) launch_trace_level_t<true>(raygen, count, g, b, st, fp, bp, io);
-    else launch_trace_level_t<false>(raygen, count, g, b, st, fp, bp, io);
+    const bool qn = fp.qnodes != nullptr;
+    if (raygen) {
+        if (qn) launch_trace_level_t<true, true, false>(count, g, b, st, fp, bp, io);
+        else launch_trace_level_t<true, false, false>(count, g, b, st, fp, bp, io);
+    } else if (staged_starts()) {
+        if (qn) launch_trace_level_t<false, true, true>(count, g, b, st, fp, bp, io);
+        else launch_trace_level_t<false, false, true>(count, g, b, st, fp, bp, io);
+    } else {
+        if (qn) launch_trace_level_t<false, true, false>(count, g, b, st, fp, bp, io);
+        else launch_trace_level_t<false, false, false>(count, g, b, st, fp, bp, io);
+    }
 }
 
 void launch_setup(bool level0, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp, const SetupIO& io,

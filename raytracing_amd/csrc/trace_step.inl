@@ -19,7 +19,9 @@
                     if (lane == first_lane) c_wnode++;
                     // node steps in which every participating lane stands on the SAME node
                     const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+#ifndef TRR_COUNT_WAIT
                     if (__ballot(cur == cur0) == am && lane == first_lane) c_wuni++;
+#endif
                 }
                 float t0, t1, t2, t3;
                 uint32_t r0, r1, r2, r3;

@@ -6,6 +6,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 from raytracing_amd import _native as N  # noqa: E402
+if os.environ.get("TRR_LIB"):
+    N.LIB_PATH = os.environ["TRR_LIB"]
 from raytracing_amd import standin  # noqa: E402
 from raytracing_amd.raytracer import Raytracer  # noqa: E402
 
@@ -36,5 +38,9 @@ print(f"  per 64 rays: wave node steps {st.wave_node_steps * g:.2f} tri steps {s
 print(f"  lane utilisation: node steps {st.node_visits / max(1, 64 * st.wave_node_steps):.3f}, "
       f"lanes with a ray per outer step {st.wave_lane_steps / max(1, 64 * st.wave_outer_steps):.3f}, "
       f"uniform node steps {st.wave_uniform_node_steps / max(1, st.wave_node_steps):.3f}")
+leaf_boxes = st.box_tests - 4 * st.node_visits
+print(f"  leaf steps: own-box tests per wave step {leaf_boxes / max(1, st.wave_tri_steps):.1f} of 128 lane-slots = {leaf_boxes / max(1, 128 * st.wave_tri_steps):.3f}")
+if os.environ.get("TRR_COUNT_WAIT"):   # a -DTRR_COUNT_WAIT build counts waiting lanes in the uniform-node-step counter
+    print(f"  lanes waiting with a finished traversal per outer step {st.wave_uniform_node_steps / max(1, 64 * st.wave_outer_steps):.3f}")
 print(f"  ms_total {st.ms_total:.2f} trace {st.ms_trace:.2f} shade {st.ms_shade:.2f} launches {st.trace_launches} overflows {st.queue_overflows}")
 rt.close()

@@ -183,6 +183,9 @@ class _BitWriter:
         return bytes(self.out)
 
 
+LENGTH_HOOK = None   # callable(dict symbol -> code length) -> dict; None = write honest tables
+
+
 def _huf_compress(symbols):
     freq = {}
     for s in symbols:
@@ -205,6 +208,8 @@ def _huf_compress(symbols):
             heapq.heappush(heap, (f1 + f2, tick, s1 + s2))
             tick += 1
     assert max(length.values()) <= 58
+    if LENGTH_HOOK is not None:   # tests of the decoder's table checks: tamper with the code lengths before they are packed
+        length = LENGTH_HOOK(dict(length))
     count = [0] * 59
     for l in length.values():
         count[l] += 1

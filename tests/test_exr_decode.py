@@ -165,6 +165,38 @@ def test_unsupported_and_broken_files_fail_like_a_failed_image_open(tmp_path):
             decode(stub, tmp_path)
 
 
+def test_piz_with_an_over_subscribed_code_table_is_refused(tmp_path, monkeypatch):
+    """A PIZ code-length table whose Kraft sum exceeds 1 (here: every symbol claims a 1-bit code) gives canonical codes that
+    do not fit their length; the decoder must refuse the table, not index its look-up table with them."""
+    w, h = 64, 32   # smooth ramps: the PIZ block is smaller than the raw one, so the writer keeps it (a noisy block is stored raw)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    r, g, b = x / w, y / h, np.full((h, w), 0.25, np.float32)
+    path = str(tmp_path / "bad_table.exr")
+    for claimed in (1, 2):   # every symbol claims a 1-bit code; every symbol claims a 2-bit code
+        monkeypatch.setattr(W, "LENGTH_HOOK", lambda length, c=claimed: {s: (c if l else 0) for s, l in length.items()})
+        W.STATS.update(compressed=0, raw=0)
+        W.write_exr(path, {"R": (W.HALF, r), "G": (W.HALF, g), "B": (W.HALF, b)}, W.PIZ)
+        assert W.STATS["compressed"] == 1 and W.STATS["raw"] == 0
+        with pytest.raises(RuntimeError, match="over-subscribed"):
+            decode(path, tmp_path)
+    monkeypatch.setattr(W, "LENGTH_HOOK", None)   # the same picture with an honest table decodes
+    W.write_exr(path, {"R": (W.HALF, r), "G": (W.HALF, g), "B": (W.HALF, b)}, W.PIZ)
+    assert decode(path, tmp_path).shape == (h, w, 3)
+
+
+def test_a_header_that_claims_an_absurd_size_is_refused_before_anything_is_allocated(tmp_path):
+    w, h = 8, 8
+    r, g, b = picture(w, h, 3)
+    path = str(tmp_path / "huge.exr")
+    W.write_exr(path, {"R": (W.HALF, r), "G": (W.HALF, g), "B": (W.HALF, b)}, W.NONE)
+    d = bytearray(open(path, "rb").read())
+    i = d.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    d[i:i + 16] = np.array([0, 0, 60000, 60000], "<i4").tobytes()   # 60001 x 60001 pixels
+    open(path, "wb").write(d)
+    with pytest.raises(RuntimeError, match="EXR|dimensions"):
+        decode(path, tmp_path)
+
+
 def test_the_python_loader_reads_exr_through_the_same_decoder(tmp_path):
     from raytracing_amd import loader
     w, h = 48, 24

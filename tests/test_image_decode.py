@@ -117,3 +117,20 @@ def test_unsupported_files_fail_like_a_failed_image_open(tmp_path):
     img.save(ok, compression="tiff_lzw")
     open(cut, "wb").write(open(ok, "rb").read()[:200])
     assert "Failed to load image" in cpp_decode(cut, tmp_path, expect_rc=2)
+
+
+def test_jpeg_scan_header_with_a_table_selector_out_of_range_is_refused(tmp_path):
+    """SOS names Huffman tables by a 4-bit selector each; only 0..3 exist (dc[4] / ac[4] in the decoder).  A selector above 3
+    must be a decode error, not an out-of-bounds table read."""
+    ok = os.path.join(str(tmp_path), "ok.jpg")
+    PIL.fromarray(_pattern(32, 24, 4), "RGB").save(ok, quality=90)
+    data = bytearray(open(ok, "rb").read())
+    sos = data.index(b"\xff\xda")
+    ns = data[sos + 4]
+    assert ns == 3
+    for sel in (0x40, 0x0F, 0xFF):   # Td = 4, Ta = 15, both
+        bad = bytearray(data)
+        bad[sos + 4 + 2] = sel        # first component's (Td << 4) | Ta
+        path = os.path.join(str(tmp_path), f"bad_{sel:02x}.jpg")
+        open(path, "wb").write(bad)
+        assert "bad JPEG table selector" in cpp_decode(path, tmp_path, expect_rc=2)
