@@ -883,8 +883,10 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
 // divisions of bvh::Ray::new (object.rs:186-195) -- and parks them in LDS (48 B per ray); a lane whose ray has ended then
 // STARTS its next ray with three LDS reads and the two matrix products, no division, no square root, no memory round trip.
 // The arithmetic of a ray is the same as in the transition block below (same functions, same operands), so the same bits.
-// What it buys: ray ends no longer have to wait for 42 lanes of company to make the long start block worth its while
-// (END_MIN instead of REFILL_MIN): finished lanes were 25 % of all lane-steps of the 4K x 16 spp frame.
+// The idea: ray ends no longer have to wait for 42 lanes of company to make the long start block worth its while (END_MIN
+// instead of REFILL_MIN) -- finished lanes are 25 % of all lane-steps of the 4K x 16 spp frame.  Measured: no gain on its
+// own (lanes that start together stay in step, which the wave-uniform vote needs more than it needs busy lanes) and 8 %
+// slower with three batches in flight (its 12 KB of LDS crowd out the other batches' blocks): opt-in, TRR_STAGE=1.
 template <bool RAYGEN, bool COUNT, bool QN, bool ST>
 __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_level(FrameParams fp, BatchParams bp, LevelIO io) {
     static_assert(!(RAYGEN && ST), "staged ray starts are for the secondary-ray launches");
@@ -1745,11 +1747,12 @@ void launch_trace(bool count, uint32_t grid, hipStream_t st, const FrameParams& 
     else hipLaunchKernelGGL((k_trace<false>), g, b, 0, st, a);
 }
 
-// the level kernels read the 64-B quantised nodes when the frame has them (fp.qnodes), the exact ones otherwise; the
-// secondary-ray launches use the staged ray starts unless TRR_STAGE=0 (experiments, tests of the older path)
+// the level kernels read the 64-B quantised nodes when the frame has them (fp.qnodes), the exact ones otherwise.
+// TRR_STAGE=1 switches the secondary-ray launches to the staged ray starts (k_trace_level<.., ST>): same image, measured
+// 8 % slower on the 4K x 16 spp frame (profiles/r03_staged_starts_ab.txt), so it is opt-in, for experiments and its test.
 static bool staged_starts() {
-    static const bool on = [] { const char* e = std::getenv("TRR_STAGE"); return !(e && e[0] == '0'); }();
-    return on;
+    const char* e = std::getenv("TRR_STAGE");
+    return e && e[0] == '1';
 }
 template <bool RAYGEN, bool COUNT, bool QN, bool ST>
 static int level_bpc_one() {
@@ -1760,10 +1763,12 @@ static int level_bpc_one() {
 int level_blocks_per_cu(bool raygen, bool count) {
     if (raygen) return count ? std::min(level_bpc_one<true, true, false, false>(), level_bpc_one<true, true, true, false>())
                              : std::min(level_bpc_one<true, false, false, false>(), level_bpc_one<true, false, true, false>());
-    if (staged_starts()) return count ? std::min(level_bpc_one<false, true, false, true>(), level_bpc_one<false, true, true, true>())
-                                      : std::min(level_bpc_one<false, false, false, true>(), level_bpc_one<false, false, true, true>());
-    return count ? std::min(level_bpc_one<false, true, false, false>(), level_bpc_one<false, true, true, false>())
-                 : std::min(level_bpc_one<false, false, false, false>(), level_bpc_one<false, false, true, false>());
+    // asked once per context: the smallest over both ray-start forms, either of which a later launch may use
+    const int st = count ? std::min(level_bpc_one<false, true, false, true>(), level_bpc_one<false, true, true, true>())
+                         : std::min(level_bpc_one<false, false, false, true>(), level_bpc_one<false, false, true, true>());
+    const int pl = count ? std::min(level_bpc_one<false, true, false, false>(), level_bpc_one<false, true, true, false>())
+                         : std::min(level_bpc_one<false, false, false, false>(), level_bpc_one<false, false, true, false>());
+    return std::min(st, pl);
 }
 
 template <bool RAYGEN, bool QN, bool ST>
