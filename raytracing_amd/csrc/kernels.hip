@@ -163,7 +163,18 @@ DEV F3 primary_dir(const FrameParams& fp, uint32_t x, uint32_t y, uint32_t si) {
 // triangle.rs:53-85).  Persistent wavefronts pull rays from a device-side work counter; lanes whose ray
 // has finished are re-filled (ballot + one atomic per wavefront) once enough of them are idle.
 // ------------------------------------------------------------------------------------------------
-constexpr int TRACE_THREADS = 256;
+// Threads per block of the trace kernels.  The host side counts blocks in units of 256 threads (grid sizes, resident blocks
+// per CU, spill / queue sizes): the launchers below convert.
+#ifndef TRR_TRACE_THREADS
+#define TRR_TRACE_THREADS 256
+#endif
+constexpr int TRACE_THREADS = TRR_TRACE_THREADS;
+static_assert(TRACE_THREADS == 64 || TRACE_THREADS == 128 || TRACE_THREADS == 256, "trace blocks are 1, 2 or 4 wavefronts");
+constexpr int BLOCKS_PER_256 = 256 / TRACE_THREADS;
+#ifndef TRR_RESOLVE_THREADS
+#define TRR_RESOLVE_THREADS 256
+#endif
+constexpr int RESOLVE_THREADS = TRR_RESOLVE_THREADS;
 #ifdef TRR_WAVES_PER_EU
 #define TRR_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(TRR_WAVES_PER_EU, 8)))
 #else
@@ -1259,9 +1270,22 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
 }
 
 // k_setup: one chain ray's closest hit -> shaded-hit record + secondary rays (mod.rs:116-153, 199-206; object.rs:198-219)
-// with full wavefronts.  Queue slots are claimed with one atomic per wavefront and queue.
+// with full wavefronts.  Queue slots are claimed with ONE atomic per block, round and queue: the wavefronts of a block put
+// their counts into LDS, thread 0 claims the block's range, every wavefront takes its part of it.  Same-address atomics
+// serialise at about 10 ns each on this device, and one per wavefront and round (55 k per queue in a level-0 launch of the
+// 4K x 16 spp frame) was most of this kernel's time.  The barriers are reached by every wavefront in every round (the
+// round count is uniform over the grid); the LDS cells alternate between rounds, so a wavefront that runs ahead cannot
+// overwrite what a slower one still reads.
+#ifndef TRR_SETUP_THREADS
+#define TRR_SETUP_THREADS 128   // same box, lone 4K x 16 spp frame: one atomic per wavefront 27.75 ms | blocks of 128: 26.7 | 256: 27.15 | 512: 28.8 | 1024: 29.2 (profiles/r03_setup_block_claims_ab.txt)
+#endif
+constexpr int SETUP_THREADS = TRR_SETUP_THREADS;
 template <bool LEVEL0>
-__global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, SetupIO io, uint32_t lvl) {
+__global__ void __launch_bounds__(SETUP_THREADS) k_setup(FrameParams fp, BatchParams bp, SetupIO io, uint32_t lvl) {
+    constexpr uint32_t NW = SETUP_THREADS / 64;
+    __shared__ uint32_t s_cnt[2][2][NW];    // [round parity][shadow | chain][wavefront]
+    __shared__ uint32_t s_base[2][2];       // [round parity][shadow | chain]
+    const uint32_t wv = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = LEVEL0 ? bp.n_samples : *io.n_chain_in;
     const uint32_t L = fp.n_lights;
@@ -1343,21 +1367,25 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
             }
         }
         // ---- shadow rays: mod.rs:149-153, one per light, grouped per light inside the wavefront's chunk ----
-        unsigned long long hm = __ballot(hit);
-        if (hm != 0ull && L > 0 && io.cull != 0u && L <= 64u) {
+        const unsigned long long hm = __ballot(hit);
+        const unsigned long long sm = __ballot(spawn);
+        const uint32_t nh = (uint32_t)__popcll(hm), ns = (uint32_t)__popcll(sm);
+        const bool culling = io.cull != 0u && L <= 64u;
+        unsigned long long keep = 0ull;   // per lane: bit l = light l's shadow ray is traced
+        uint32_t total_rays = nh * L;
+        if (hm != 0ull && L > 0 && culling) {
             // Shadow-ray cull.  A light whose diffuse AND specular intensities (mod.rs:176-177, 184-195) are exactly 0.0
             // adds exactly nothing to the colour whatever its shadow ray finds (mod.rs:171-173 skips it, or :178 / :196
             // add a colour times 0.0), unless the material is reflective (the `continue` of :171-173 would also skip the
             // reflection term, :207) -- so that ray is not traced: the pair's occluder code says OCC_CULLED and the
             // resolve pass skips the light.  The two intensities are evaluated here with the resolve pass's own
             // operations; 0.0 * li is 0.0 only for a finite li, NaN otherwise (then the ray is traced).
-            unsigned long long keep = 0ull;   // per lane: bit l = light l's shadow ray is traced
             if (hit) {
                 bool specular = false;
-                float ns = 1.0f;
+                float ns_exp = 1.0f;
                 if (hit_mat >= 0) {
                     const MatRec* m = fp.mats + hit_mat;
-                    if (m->flags & 4u) ns = m->ns;
+                    if (m->flags & 4u) ns_exp = m->ns;
                     specular = (m->illum == 2);
                 }
                 const bool reflective = hit_reflective;
@@ -1370,22 +1398,34 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
                     const float di = rmax(dot(ld, N), 0.0f) * li;
                     bool dark = !reflective && di == 0.0f;
                     if (dark && specular) {
-                        const float sint = powf(rmax(dot(ld, rv), 0.0f), ns) * li;
+                        const float sint = powf(rmax(dot(ld, rv), 0.0f), ns_exp) * li;
                         dark = sint == 0.0f;
                     }
                     if (dark) io.occ[((size_t)lvl * L + l) * cap + sample] = OCC_CULLED;
                     else keep |= 1ull << l;
                 }
             }
-            uint32_t total_rays = 0;
+            total_rays = 0;
             for (uint32_t l = 0; l < L; ++l) total_rays += (uint32_t)__popcll(__ballot((keep >> l) & 1ull));
-            n_sh += (uint32_t)__popcll(hm) * L;   // the statistics count the algorithm's rays, traced or culled
-            n_cull += (uint32_t)__popcll(hm) * L - total_rays;
-            uint32_t base = 0;
-            if (total_rays != 0u) {
-                if (lane == 0) base = atomicAdd(io.n_shadow_out, total_rays);
-                base = __shfl(base, 0);
-            }
+        }
+        n_sh += nh * L;   // the statistics count the algorithm's rays, traced or culled
+        n_cull += nh * L - total_rays;
+        n_ch += ns;
+        // ---- the block's queue ranges: one atomic per queue for all its wavefronts -------------------------------------
+        const uint32_t par = it & 1u;
+        if (lane == 0) { s_cnt[par][0][wv] = total_rays; s_cnt[par][1][wv] = ns; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t_sh = 0, t_ch = 0;
+            for (uint32_t k = 0; k < NW; ++k) { t_sh += s_cnt[par][0][k]; t_ch += s_cnt[par][1][k]; }
+            s_base[par][0] = t_sh != 0u ? atomicAdd(io.n_shadow_out, t_sh) : 0u;
+            s_base[par][1] = t_ch != 0u ? atomicAdd(io.n_chain_out, t_ch) : 0u;
+        }
+        __syncthreads();
+        uint32_t base = s_base[par][0], base_ch = s_base[par][1];
+        for (uint32_t k = 0; k < NW; ++k)
+            if (k < wv) { base += s_cnt[par][0][k]; base_ch += s_cnt[par][1][k]; }
+        if (hm != 0ull && L > 0 && culling) {
             for (uint32_t l = 0; l < L && total_rays != 0u; ++l) {
                 const bool mine = ((keep >> l) & 1ull) != 0ull;
                 const unsigned long long km = __ballot(mine);
@@ -1405,11 +1445,6 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
                 base += (uint32_t)__popcll(km);
             }
         } else if (hm != 0ull && L > 0) {
-            uint32_t nh = (uint32_t)__popcll(hm);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(io.n_shadow_out, nh * L);
-            base = __shfl(base, 0);
-            n_sh += nh * L;
             uint32_t rank = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
             if (hit && io.shadow_compact != 0u) {
                 // compact entries: the shaded point and (sample, light); the trace kernel rebuilds the ray
@@ -1427,20 +1462,12 @@ __global__ void __launch_bounds__(256) k_setup(FrameParams fp, BatchParams bp, S
             }
         }
         // ---- reflection ray: mod.rs:203-206 (traced once per hit; the value is light-independent) ----------
-        unsigned long long sm = __ballot(spawn);
-        if (sm != 0ull) {
-            uint32_t ns = (uint32_t)__popcll(sm);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(io.n_chain_out, ns);
-            base = __shfl(base, 0);
-            n_ch += ns;
-            uint32_t rank = (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
-            if (spawn) {
-                F3 o = P + scale(N, fp.delta), d = reflect(D, N);
-                float4* e = io.chain_out + (size_t)(base + rank) * 2u;
-                e[0] = make_float4(o.x, o.y, o.z, d.x);
-                e[1] = make_float4(d.y, d.z, __uint_as_float(sample), __uint_as_float(lvl + 1u));
-            }
+        if (spawn) {
+            const uint32_t rank = (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+            F3 o = P + scale(N, fp.delta), d = reflect(D, N);
+            float4* e = io.chain_out + (size_t)(base_ch + rank) * 2u;
+            e[0] = make_float4(o.x, o.y, o.z, d.x);
+            e[1] = make_float4(d.y, d.z, __uint_as_float(sample), __uint_as_float(lvl + 1u));
         }
     }
     if (lane == 0 && (n_sh | n_ch) != 0u) {   // the ray statistics of trr_stats
@@ -1548,7 +1575,7 @@ DEV F3 resolve_sample(const FrameParams& fp, const BatchParams& bp, const Resolv
     }
 }
 
-__global__ void __launch_bounds__(256) k_resolve_samples(FrameParams fp, BatchParams bp, ResolveIO io) {
+__global__ void __launch_bounds__(RESOLVE_THREADS) k_resolve_samples(FrameParams fp, BatchParams bp, ResolveIO io) {
     const size_t cap = bp.cap;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < bp.n_samples; s += gridDim.x * blockDim.x) {
         const F3 R = resolve_sample(fp, bp, io, s);
@@ -1563,7 +1590,7 @@ __global__ void __launch_bounds__(256) k_resolve_samples(FrameParams fp, BatchPa
 // sequential sum (mod.rs:248-249) -- and the first lane of the group writes the pixel.  The samples' colours never go to
 // memory (12 B written + 12 B read per sample saved, and a launch).  Whole wavefronts iterate together: the shuffles need
 // every lane present.
-__global__ void __launch_bounds__(256) k_resolve_fused(FrameParams fp, BatchParams bp, ResolveIO io) {
+__global__ void __launch_bounds__(RESOLVE_THREADS) k_resolve_fused(FrameParams fp, BatchParams bp, ResolveIO io) {
     const uint32_t spp = fp.spp;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t base = lane & ~(spp - 1u);
@@ -1592,7 +1619,7 @@ __global__ void __launch_bounds__(256) k_resolve_fused(FrameParams fp, BatchPara
 
 // Pass 2, one thread per PIXEL: sum of the pixel's samples in ascending order, mean (mod.rs:248-249), quantise
 // (render.rs:134-140), store into the shard's strip.
-__global__ void __launch_bounds__(256) k_resolve_pixels(FrameParams fp, BatchParams bp, ResolveIO io) {
+__global__ void __launch_bounds__(RESOLVE_THREADS) k_resolve_pixels(FrameParams fp, BatchParams bp, ResolveIO io) {
     const size_t cap = bp.cap;
     const uint32_t spp = fp.spp;
     if (spp >= 2u && spp <= 64u && (spp & (spp - 1u)) == 0u) {
@@ -1733,14 +1760,15 @@ int trace_blocks_per_cu(bool count) {
     hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<true>, TRACE_THREADS, 0)
                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<false>, TRACE_THREADS, 0);
     if (e != hipSuccess || nb < 1) nb = 1;
-    return nb;
+    return std::max(1, nb / BLOCKS_PER_256);   // in 256-thread units
 }
 
-size_t trace_spill_bytes(uint32_t grid) { return (size_t)grid * TRACE_THREADS * STACK_SPILL * sizeof(uint2); }
-size_t trace_queue_bytes(uint32_t grid, uint32_t qcap) { return (size_t)grid * (TRACE_THREADS / 64) * qcap * 32; }
+// `grid` in 256-thread units
+size_t trace_spill_bytes(uint32_t grid) { return (size_t)grid * 256 * STACK_SPILL * sizeof(uint2); }
+size_t trace_queue_bytes(uint32_t grid, uint32_t qcap) { return (size_t)grid * 4 * qcap * 32; }
 
 void launch_trace(bool count, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp, const TraceIO& io) {
-    dim3 g(grid), b(TRACE_THREADS);
+    dim3 g(grid * BLOCKS_PER_256), b(TRACE_THREADS);
     TraceArgs a;
     a.fp = fp; a.bp = bp; a.io = io;
     if (count) hipLaunchKernelGGL((k_trace<true>), g, b, 0, st, a);
@@ -1758,7 +1786,7 @@ template <bool RAYGEN, bool COUNT, bool QN, bool ST>
 static int level_bpc_one() {
     int nb = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_level<RAYGEN, COUNT, QN, ST>, TRACE_THREADS, 0);
-    return (e != hipSuccess || nb < 1) ? 1 : nb;
+    return (e != hipSuccess || nb < 1) ? 1 : std::max(1, nb / BLOCKS_PER_256);   // in 256-thread units
 }
 int level_blocks_per_cu(bool raygen, bool count) {
     if (raygen) return count ? std::min(level_bpc_one<true, true, false, false>(), level_bpc_one<true, true, true, false>())
@@ -1778,7 +1806,7 @@ static void launch_trace_level_t(bool count, dim3 g, dim3 b, hipStream_t st, con
 }
 void launch_trace_level(bool raygen, bool count, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
                         const LevelIO& io) {
-    dim3 g(grid), b(TRACE_THREADS);
+    dim3 g(grid * BLOCKS_PER_256), b(TRACE_THREADS);
     const bool qn = fp.qnodes != nullptr;
     if (raygen) {
         if (qn) launch_trace_level_t<true, true, false>(count, g, b, st, fp, bp, io);
@@ -1794,7 +1822,8 @@ void launch_trace_level(bool raygen, bool count, uint32_t grid, hipStream_t st, 
 
 void launch_setup(bool level0, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp, const SetupIO& io,
                   uint32_t lvl) {
-    dim3 g(grid), b(256);
+    // `grid` counts 256-thread blocks (the caller's unit for all the streaming kernels)
+    dim3 g(std::max(1u, (grid * 256u + SETUP_THREADS - 1) / SETUP_THREADS)), b(SETUP_THREADS);
     if (level0) hipLaunchKernelGGL((k_setup<true>), g, b, 0, st, fp, bp, io, lvl);
     else hipLaunchKernelGGL((k_setup<false>), g, b, 0, st, fp, bp, io, lvl);
 }
@@ -1807,13 +1836,14 @@ static bool resolve_two_pass() {
 void launch_resolve(uint32_t grid_samples, uint32_t grid_pixels, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
                     const ResolveIO& io) {
     const bool pow2 = fp.spp >= 1u && fp.spp <= 64u && (fp.spp & (fp.spp - 1u)) == 0u;
+    constexpr uint32_t RB = 256 / RESOLVE_THREADS;   // the grids arrive in 256-thread units
     if (pow2 && !resolve_two_pass()) {
-        hipLaunchKernelGGL(k_resolve_fused, dim3(grid_samples), dim3(256), 0, st, fp, bp, io);
+        hipLaunchKernelGGL(k_resolve_fused, dim3(grid_samples * RB), dim3(RESOLVE_THREADS), 0, st, fp, bp, io);
         return;
     }
-    hipLaunchKernelGGL(k_resolve_samples, dim3(grid_samples), dim3(256), 0, st, fp, bp, io);
+    hipLaunchKernelGGL(k_resolve_samples, dim3(grid_samples * RB), dim3(RESOLVE_THREADS), 0, st, fp, bp, io);
     const bool per_sample = pow2 && fp.spp >= 2u;   // k_resolve_pixels' coalesced form
-    hipLaunchKernelGGL(k_resolve_pixels, dim3(per_sample ? grid_samples : grid_pixels), dim3(256), 0, st, fp, bp, io);
+    hipLaunchKernelGGL(k_resolve_pixels, dim3((per_sample ? grid_samples : grid_pixels) * RB), dim3(RESOLVE_THREADS), 0, st, fp, bp, io);
 }
 
 void launch_assemble(hipStream_t st, uint32_t width, uint32_t height, uint32_t bw, uint32_t bh, uint32_t nbx, uint32_t nby,

@@ -1,6 +1,6 @@
 import csv, sys, glob, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
-K = int(sys.argv[2])
+K = float(sys.argv[2])   # frames in the SECOND HALF of the dispatches (e.g. 1.5 for a 3-frame run)
 rows = [r for r in csv.DictReader(open(f)) if "trr::" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # second repetition = last half of the dispatches
