@@ -147,7 +147,8 @@ int trr_create(int device_id, trr_ctx** out);
  * all GPUs of a node by changing its trr_create call into this one.  trr_render_shard_device* and the hit-id buffers of
  * trr_render need a single-device context.  Environment: TRR_MULTI_TRANSPORT=copy exchanges the strips by peer copies
  * instead of RCCL; TRR_MULTI_ALLOW_DUPLICATES=1 lets a device be listed twice (a rehearsal of the N-device path on one
- * GPU; always peer copies).  No counterpart in the reference (it has no device). */
+ * GPU; always peer copies).  An error reported by RCCL (ncclCommInitAll, ncclGather) costs a warning on stderr, not the
+ * frame: the context exchanges its strips by peer copies from then on.  No counterpart in the reference (it has no device). */
 int trr_create_multi(const int* device_ids, int n_devices, trr_ctx** out);
 int trr_device_count(const trr_ctx* ctx);   /* devices the context drives (1 for trr_create) */
 void trr_destroy(trr_ctx* ctx);
@@ -221,7 +222,11 @@ int trr_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, 
  * in render.rs:129-130, `rgb` holds block_w*block_h RGB8 pixels row-major inside the block and is valid only during the
  * call.  Pixels of the remainder strip (render.rs:100-102) belong to no block and are never delivered.  `cancel_flag`
  * is polled and `progress` (nullable) called between batches as in trr_render.  Smaller batches mean earlier blocks
- * and a slower frame (every batch ends with the latency of its longest ray). */
+ * and a slower frame (every batch ends with the latency of its longest ray).
+ * On a context of several devices (trr_create_multi) every device renders its blocks (b % N) in batches of
+ * blocks_per_batch / N and the calling thread hands the finished batches to `sink` in ARRIVAL order, while the devices go on
+ * rendering: each block exactly once, still only on the calling thread, but not in row-major order -- the reference's
+ * `par_bridge` (render.rs:109-113) delivers in completion order too.  `progress` then also runs on the calling thread. */
 typedef void (*trr_block_cb)(void* user, uint32_t x_block, uint32_t y_block, uint32_t block_w, uint32_t block_h, const uint8_t* rgb);
 int trr_render_blocks(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t flags, uint32_t blocks_per_batch,
                       const volatile int32_t* cancel_flag, trr_block_cb sink, trr_progress_cb progress, void* user,
@@ -252,8 +257,10 @@ uint32_t trr_shard_blocks(uint32_t width, uint32_t height, uint32_t shard, uint3
  * Limit: the work set of ONE block (block_w*block_h*samples samples; the bytes per sample grow with lights x max_depth)
  * must fit the array, else TRR_ERR_INVALID with the figures in trr_last_error() -- e.g. a 1080p block at 16 spp, 4 lights,
  * max_depth 5 fits (about 4 blocks per batch); a 4K block at 16 spp does not.  Every call on a GPU shares that GPU's
- * array: calls that overlap on one GPU (two streams, two threads, two contexts of one device) race; calls queued on one
- * stream are ordered by it. */
+ * array and keeps the last call's contents.  Calls from different streams or contexts of one GPU are ordered ON THE
+ * DEVICE by one event per GPU (created with the GPU's first context; the call waits for it and records it again), so they
+ * queue up behind each other instead of racing -- they never overlap, which is the price of the one array.  Two host
+ * THREADS calling at the same moment are serialised by a mutex for the few microseconds of queueing. */
 int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t shard,
                                     uint32_t n_shards, void* strip_dev, size_t strip_bytes, void* stream);
 size_t trr_noalloc_scratch_bytes(void);

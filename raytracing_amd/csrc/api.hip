@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +52,12 @@ using namespace trr;
 // its own copy at its own address) and everything below uses that pointer (ctx->scratch), never the name.
 static constexpr size_t SCRATCH_BYTES = 256ull << 20;   // 256 MiB of the 288 GB
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+// Every context and stream of a GPU carves its work set from offset 0 of that GPU's array, so two calls must not overlap on
+// the device.  One event per device, created with the device's first context (nothing is allocated at call time): a call
+// makes its stream wait for the event before it touches the array and records it after its last batch, so callers on
+// different streams or contexts of one GPU queue up behind each other instead of racing.
+static std::mutex g_scratch_mu;
+static hipEvent_t g_scratch_ev[64] = {};
 
 // ---- opaque handles --------------------------------------------------------------------------------------
 struct DevBuf {
@@ -82,10 +89,12 @@ struct trr_ctx {
     int bpc[2] = {0, 0};                 // resident 256-thread blocks per CU of k_trace<COUNT> (occupancy query, once)
     int bpc_level[2][2] = {{0, 0}, {0, 0}};   // ... of k_trace_level<RAYGEN, COUNT>
     unsigned char* scratch = nullptr;    // this device's copy of the static `scratch` array (hipGetSymbolAddress in trr_create)
+    hipEvent_t scratch_ev = nullptr;     // this DEVICE's event that orders the users of that array (shared by its contexts)
     // a multi-device context (trr_create_multi) owns one plain context per device and drives them; it has no streams or
     // work buffers of its own.  subs[0] is the root: it receives the gathered strips and assembles the frame.
     std::vector<trr_ctx*> subs;
     bool duplicate_devices = false;      // (rehearsal on one GPU) a device is listed twice: strips are exchanged by peer copies
+    bool rccl_failed = false;            // RCCL reported an error once: this context exchanges strips by peer copies from then on
     std::vector<void*> comms;            // ncclComm_t per device (RCCL, loaded on demand); empty while no gather is needed
     DevBuf gathered;                     // on subs[0]'s device: the strips of all devices
     uint32_t rotate = 0;                 // round-robin start lane of single-batch frames
@@ -113,7 +122,18 @@ struct trr_ctx {
 // HIP's default of 4 hardware queues per process is fewer than the streams a frame uses (up to three lanes, each with two
 // more streams in the split schedule): ask for 16 when this library is loaded before the HIP runtime starts and the host has
 // not chosen a value itself.
-static const int g_hw_queues_env = [] { return ::setenv("GPU_MAX_HW_QUEUES", "16", 0); }();
+// The value is recorded ONCE, here, before anything of this library can have started the HIP runtime: what the host had set
+// when the library was loaded, else the 16 this initialiser sets itself (documented in INTEGRATION.md; a host that wants HIP's
+// default exports GPU_MAX_HW_QUEUES=4 before loading the library).  The render path reads the recorded value, never the
+// environment again: a change made after HIP has started says nothing about the queues HIP really has.
+static const int g_hw_queues = [] {
+    if (const char* e = std::getenv("GPU_MAX_HW_QUEUES")) {
+        const int v = std::atoi(e);
+        return v > 0 ? v : 4;
+    }
+    (void)::setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    return 16;
+}();
 
 struct trr_scene {
     trr_ctx* ctx = nullptr;
@@ -194,6 +214,9 @@ static int multi_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint
                               uint32_t n_textures, uint32_t build, trr_scene** out);
 static int multi_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t flags, uint8_t* rgb_out,
                         const volatile int32_t* cancel_flag, trr_progress_cb progress, void* user, trr_stats* stats_out);
+static int multi_render_blocks(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t flags, uint32_t blocks_per_batch,
+                               const volatile int32_t* cancel_flag, trr_block_cb sink, trr_progress_cb progress, void* user, trr_stats* stats_out);
+static void add_stats(trr_stats& sum, const trr_stats& a);
 
 // ---- extern "C" ---------------------------------------------------------------------------------------------
 extern "C" {
@@ -248,6 +271,15 @@ int trr_create(int device_id, trr_ctx** out) {
     if (e != hipSuccess || ctx->scratch == nullptr) {
         trr_destroy(ctx);
         return fail(nullptr, TRR_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    }
+    if (device_id < 64) {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (!g_scratch_ev[device_id] && hipEventCreateWithFlags(&g_scratch_ev[device_id], hipEventDisableTiming) != hipSuccess) {
+            g_scratch_ev[device_id] = nullptr;
+            trr_destroy(ctx);
+            return fail(nullptr, TRR_ERR_DEVICE, "hipEventCreate (scratch order) failed");
+        }
+        ctx->scratch_ev = g_scratch_ev[device_id];   // kept for the life of the process, like the array
     }
     // resident 256-thread blocks per CU of the two k_trace instantiations (each has its own register count)
     for (int cn = 0; cn < 2; ++cn) ctx->bpc[cn] = std::max(1, std::min(trace_blocks_per_cu(cn != 0), 8));
@@ -1074,6 +1106,8 @@ struct BatchGrids {
     uint32_t followups;        // persistent: launches after the first that drain what the launch before spilled (0 = none)
     uint32_t chunk_min[2];     // persistent: smallest claim of work items per wavefront in the first / the follow-up launches
     uint32_t raygen, secondary;   // levels: grids of the camera-ray and the secondary-ray launches
+    uint32_t chain;               // levels, split: grid of a launch that traces reflection rays only (the batch's dependent chain)
+    uint32_t aux_deep;            // largest grid of the set-up passes of levels >= 1
     uint32_t levels;              // levels: chain levels that can hold a hit (1 when no material is a mirror, else max_depth)
     uint32_t cull;                // levels: 1 = k_setup culls the shadow rays of lights that add exactly nothing (kernels.hip)
     uint32_t split;               // levels: 1 = reflection rays and shadow rays in launches of their own, on streams of their own
@@ -1166,7 +1200,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
                 sio.n_chain_out = cw + CW_NCHAIN + lvl + 1;
                 sio.counters = kc;
                 ev_begin(1, s_);
-                launch_setup(lvl == 0, aux_grid, s_, fp, bp, sio, lvl);
+                launch_setup(lvl == 0, lvl == 0 ? aux_grid : std::min(aux_grid, g.aux_deep), s_, fp, bp, sio, lvl);
                 ev_end(s_);
                 (void)hipEventRecord(w.sync_ev[2 * lvl], s_);
                 // this level's shadow rays, off the chain
@@ -1192,7 +1226,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
                     tc.work_counter = cw + CW_WORK + CW_WORK_STRIDE * (2 * lvl + 1);
                     tc.first_obj = nullptr; tc.first_tri = nullptr;
                     ev_begin(0, s_);
-                    launch_trace_level(false, count, g.secondary, s_, fp, bp, tc);
+                    launch_trace_level(false, count, g.chain, s_, fp, bp, tc);
                     ev_end(s_);
                 }
             }
@@ -1221,7 +1255,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
             sio.n_chain_out = cw + CW_NCHAIN + lvl + 1;
             sio.counters = kc;
             ev_begin(1, s_);
-            launch_setup(lvl == 0, aux_grid, s_, fp, bp, sio, lvl);
+            launch_setup(lvl == 0, lvl == 0 ? aux_grid : std::min(aux_grid, g.aux_deep), s_, fp, bp, sio, lvl);
             ev_end(s_);
             if (fp.max_depth == 0) break;
             if (lvl >= g.drain_level && lvl + 1 < n_levels) {
@@ -1402,6 +1436,10 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     grids.chunk_min[0] = 64; grids.chunk_min[1] = 16;
     grids.raygen = n_cu * (uint32_t)bpc_r;
     grids.secondary = n_cu * (uint32_t)bpc_s;
+    grids.chain = grids.secondary;
+    grids.aux_deep = grids.aux_max;
+    if (const char* e = std::getenv("TRR_GRID_CHAIN_BPC")) grids.chain = n_cu * (uint32_t)std::min(bpc_s, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("TRR_GRID_SETUP_DEEP")) grids.aux_deep = n_cu * (uint32_t)std::min(8, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("TRR_FOLLOWUPS")) grids.followups = (uint32_t)std::max(0, std::atoi(e));
     // Levels-then-drain (measured, ms per frame without / with drain from level 2: a lone 4K x 16 spp frame 32.3 / 31.5, an
     // eighth of it 5.64 / 5.42, 4K mirrors max_depth 9 15.8 / 14.9): a caller that waits for every frame gains what the
@@ -1421,9 +1459,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     // half 16.3 / 16.0, 4K mirrors max_depth 9 15.4 / 14.5; the whole frame 29.9 / 30.8 (nine persistent launches at once
     // crowd each other), so it keeps the plain levels.  TRR_SPLIT=0|1 overrides.
     {
-        const char* e_q = std::getenv("GPU_MAX_HW_QUEUES");
-        const int hw_queues = e_q ? std::atoi(e_q) : 4;
-        grids.split = (hw_queues >= 8 && total_samples <= (1ull << 26) && grids.levels >= 2) ? 1u : 0u;
+        grids.split = (g_hw_queues >= 8 && total_samples <= (1ull << 26) && grids.levels >= 2) ? 1u : 0u;
     }
     if (const char* e = std::getenv("TRR_SPLIT")) grids.split = std::atoi(e) != 0 ? 1u : 0u;
     // a pipelined caller's small frames hide their thin deep levels behind the other frame; a big frame (four batches on three
@@ -1694,6 +1730,7 @@ int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, ui
     if (!strip_dev || strip_bytes < need_strip) return fail(ctx, TRR_ERR_INVALID, "trr_render_shard_device_noalloc: strip buffer too small");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (!ctx->scratch_ev) return fail(ctx, TRR_ERR_DEVICE, "trr_render_shard_device_noalloc: no ordering event for this device's scratch array");
 
     const bool aa = sc->settings.anti_aliasing != 0;
     const uint32_t spp = aa ? sc->settings.samples : 1u;
@@ -1711,7 +1748,8 @@ int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, ui
     grids.schedule = schedule;
     grids.trace = n_cu * (uint32_t)std::min(2, ctx->bpc[0]);
     grids.raygen = grids.secondary = n_cu * (uint32_t)std::min(2, std::min(ctx->bpc_level[0][0], ctx->bpc_level[1][0]));
-    grids.aux_max = n_cu * 8;
+    grids.chain = grids.secondary;
+    grids.aux_max = grids.aux_deep = n_cu * 8;
     grids.followups = 0;
     grids.drain_level = NO_DRAIN;   // (the drain's ray queues would take scratch from the batch)
     grids.levels = sc->any_reflective ? max_depth : std::min(max_depth, 1u);
@@ -1743,7 +1781,11 @@ int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, ui
     auto no_ev_begin = [](uint8_t, hipStream_t) {};
     auto no_ev_end = [](hipStream_t) {};
     // batches run one after the other on the caller's stream and share the one work set; the array keeps the last call's
-    // contents, so what must start at zero (queue sizes, work counters) is cleared before every batch
+    // contents, so what must start at zero (queue sizes, work counters) is cleared before every batch.  The array's previous
+    // user on this GPU (any stream, any context) is waited for first, on the device.
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);   // wait + record of one call are not interleaved with another call's
+        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->scratch_ev, 0));
     for (uint32_t first = 0; first < n_owned; first += blocks_per_batch) {
         BatchParams bp{};
         bp.first_owned = first;
@@ -1754,6 +1796,8 @@ int trr_render_shard_device_noalloc(trr_ctx* ctx, trr_scene* sc, float delta, ui
         HIPCHK(ctx, hipMemsetAsync(wv.counters, 0, RB_STRIDE, st));
         queue_batch(fp, bp, wv, grids, false, (uint8_t*)strip_dev, nullptr, nullptr, st, no_ev_begin, no_ev_end);
         HIPCHK(ctx, hipGetLastError());
+    }
+        HIPCHK(ctx, hipEventRecord(ctx->scratch_ev, st));
     }
     return TRR_OK;
 }
@@ -1781,22 +1825,9 @@ int trr_render_blocks(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_
     Tiling t;
     if (!tiling_of(w, h, &t)) return fail(ctx, TRR_ERR_RESOLUTION, "trr_render_blocks: width and height must be >= 20 (render.rs:109)");
     DeviceGuard guard;
-    if (is_multi(ctx) && ctx->subs.size() > 1) {
-        // several devices: the blocks of a frame finish within a few milliseconds of each other on different devices, so
-        // the whole frame is rendered (cancel / progress polled per batch) and its blocks are then handed over in row-major
-        // order, each exactly once, on the calling thread
-        std::vector<uint8_t> frame((size_t)w * h * 3), block((size_t)t.bw * t.bh * 3);
-        int rres = multi_render(ctx, scene, delta, max_depth, flags & ~(TRR_FLAG_DEFER_STATS | TRR_FLAG_PIPELINED), frame.data(), cancel_flag,
-                                progress, user, stats_out);
-        if (rres != TRR_OK) return rres;   // a cancelled frame delivers nothing: its blocks are not known to be final
-        for (uint32_t b = 0; b < t.nblocks; ++b) {
-            const uint32_t xb = b % t.nbx, yb = b / t.nbx;
-            for (uint32_t y = 0; y < t.bh; ++y)
-                std::memcpy(block.data() + (size_t)y * t.bw * 3, frame.data() + ((size_t)(yb * t.bh + y) * w + (size_t)xb * t.bw) * 3, (size_t)t.bw * 3);
-            sink(user, xb, yb, t.bw, t.bh, block.data());
-        }
-        return TRR_OK;
-    }
+    if (is_multi(ctx) && ctx->subs.size() > 1)
+        return multi_render_blocks(ctx, scene, delta, max_depth, flags & ~(TRR_FLAG_DEFER_STATS | TRR_FLAG_PIPELINED), blocks_per_batch, cancel_flag,
+                                   sink, progress, user, stats_out);
     if (is_multi(ctx)) { ctx = ctx->subs[0]; scene = scene->replicas[0]; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t sb = trr_strip_bytes(w, h, 1), block_bytes = (size_t)t.bw * t.bh * 3;
@@ -1971,23 +2002,35 @@ static int multi_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t ma
     if ((rc = ensure(root, root->frame, fb))) return fail(ctx, rc, root->err);
     // Strip exchange: one RCCL gather (default), or -- TRR_MULTI_TRANSPORT=copy, and always when a device is listed twice
     // (rehearsals on one GPU: RCCL refuses duplicate devices) -- one peer copy per device into the root's gather buffer.
+    // The RCCL path is three calls -- ncclCommInitAll, grouped ncclGather, ncclCommDestroy -- and has only ever run with one rank
+    // (no multi-GPU node was available to this build): any error it reports is logged and answered with the peer-copy exchange,
+    // for this frame and for the rest of the context's life, never with a failed render.  TRR_MULTI_INJECT_RCCL_FAILURE=init|gather
+    // makes the corresponding call "fail" (tests of that branch).
     const char* e_tr = std::getenv("TRR_MULTI_TRANSPORT");
-    const bool use_copy = n > 1 && (ctx->duplicate_devices || (e_tr && e_tr[0] == 'c'));
-    const bool use_rccl = !use_copy && (n > 1 || std::getenv("TRR_MULTI_FORCE_RCCL") != nullptr);
-    if (use_copy && (rc = ensure(root, ctx->gathered, sb * n))) return fail(ctx, rc, root->err);
-    if (use_rccl) {
-        if ((rc = ensure(root, ctx->gathered, sb * n))) return fail(ctx, rc, root->err);
-        if (ctx->comms.empty()) {
-            Rccl* r = rccl();
-            if (!r->error.empty()) return fail(ctx, TRR_ERR_DEVICE, r->error);
+    const char* e_inject = std::getenv("TRR_MULTI_INJECT_RCCL_FAILURE");
+    const bool force_rccl = std::getenv("TRR_MULTI_FORCE_RCCL") != nullptr;
+    const bool want_copy = ctx->duplicate_devices || (e_tr && e_tr[0] == 'c');
+    bool use_rccl = !ctx->rccl_failed && !want_copy && (n > 1 || force_rccl);
+    auto rccl_fallback = [&](const std::string& why) {
+        std::fprintf(stderr, "trayracer_hip: warning: %s; exchanging the strips by peer copies instead\n", why.c_str());
+        ctx->rccl_failed = true;
+        use_rccl = false;
+    };
+    if (use_rccl && ctx->comms.empty()) {
+        Rccl* r = rccl();
+        if (!r->error.empty()) rccl_fallback(r->error);
+        else {
             std::vector<int> devs;
             for (trr_ctx* c : ctx->subs) devs.push_back(c->device);
             std::vector<void*> comms(n, nullptr);
-            int e = r->CommInitAll(comms.data(), (int)n, devs.data());
-            if (e != 0) return fail(ctx, TRR_ERR_DEVICE, std::string("ncclCommInitAll: ") + r->GetErrorString(e));
-            ctx->comms = comms;
+            int e = (e_inject && e_inject[0] == 'i') ? -1 : r->CommInitAll(comms.data(), (int)n, devs.data());
+            if (e != 0) rccl_fallback(std::string("ncclCommInitAll: ") + (e < 0 ? "injected failure" : r->GetErrorString(e)));
+            else ctx->comms = comms;
         }
     }
+    // peer copies: asked for, needed (duplicates), or the answer to an RCCL error (also with one device, where the "peer" is itself)
+    bool use_copy = !use_rccl && (n > 1 || (force_rccl && ctx->rccl_failed));
+    if ((use_copy || use_rccl) && (rc = ensure(root, ctx->gathered, sb * n))) return fail(ctx, rc, root->err);
 
     // ---- shard renders ----
     std::vector<trr_stats> st(n);
@@ -2024,24 +2067,45 @@ static int multi_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t ma
     }
     int result = TRR_OK;
     for (uint32_t d = 0; d < n; ++d)
-        if (res[d] != TRR_OK && res[d] != TRR_ERR_CANCELLED) return fail(ctx, res[d], ctx->subs[d]->err);
-        else if (res[d] == TRR_ERR_CANCELLED) result = TRR_ERR_CANCELLED;
+        if (res[d] == TRR_ERR_CANCELLED && result == TRR_OK) result = TRR_ERR_CANCELLED;
+        else if (res[d] != TRR_OK && res[d] != TRR_ERR_CANCELLED) result = res[d];
+    if (result != TRR_OK && result != TRR_ERR_CANCELLED) {
+        // a shard failed: the other devices may still be writing their strips -- wait for all of them, then report every
+        // failed device's message
+        std::string msg;
+        for (uint32_t d = 0; d < n; ++d) {
+            trr_ctx* c = ctx->subs[d];
+            if (hipSetDevice(c->device) == hipSuccess) (void)hipStreamSynchronize(c->stream);
+            if (res[d] != TRR_OK && res[d] != TRR_ERR_CANCELLED) msg += (msg.empty() ? "device " : "; device ") + std::to_string(c->device) + ": " + c->err;
+        }
+        return fail(ctx, result, msg);
+    }
 
     // ---- the single exchange of the path: finished RGB8 strips to the first device ----
     const void* strips = root->strip.p;
     if (use_rccl) {
         Rccl* r = rccl();
-        int e = r->GroupStart();
+        std::string why;
+        int e = (e_inject && e_inject[0] == 'g') ? -1 : r->GroupStart();
+        const bool opened = e == 0;
         for (uint32_t d = 0; d < n && e == 0; ++d) {
             trr_ctx* c = ctx->subs[d];
-            if (hipSetDevice(c->device) != hipSuccess) return fail(ctx, TRR_ERR_DEVICE, "hipSetDevice failed");
+            if (hipSetDevice(c->device) != hipSuccess) { why = "hipSetDevice failed before ncclGather"; e = -2; break; }
             e = r->Gather(c->strip.p, d == 0 ? ctx->gathered.p : nullptr, sb, kNcclUint8, 0, ctx->comms[d], c->stream);
         }
-        int e2 = r->GroupEnd();
-        if (e == 0) e = e2;
-        if (e != 0) return fail(ctx, TRR_ERR_DEVICE, std::string("ncclGather: ") + r->GetErrorString(e));
-        strips = ctx->gathered.p;
-    } else if (use_copy) {
+        if (opened) {   // a group that was opened is always closed, whatever happened inside it
+            const int e2 = r->GroupEnd();
+            if (e == 0) e = e2;
+        }
+        if (e != 0) {
+            // nothing of a failed group can be trusted: drain every stream, then exchange the (still intact) strips by copies
+            for (trr_ctx* c : ctx->subs)
+                if (hipSetDevice(c->device) == hipSuccess) (void)hipStreamSynchronize(c->stream);
+            rccl_fallback(why.empty() ? std::string("ncclGather: ") + (e < 0 ? "injected failure" : r->GetErrorString(e)) : why);
+            use_copy = true;
+        } else strips = ctx->gathered.p;
+    }
+    if (use_copy) {
         for (uint32_t d = 0; d < n; ++d) {
             trr_ctx* c = ctx->subs[d];
             HIPCHK(ctx, hipSetDevice(c->device));
@@ -2062,19 +2126,123 @@ static int multi_render(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t ma
     }
     if (stats_out) {
         trr_stats sum{};
-        for (const trr_stats& a : st) {
-            sum.rays_primary += a.rays_primary; sum.rays_shadow += a.rays_shadow; sum.rays_reflection += a.rays_reflection;
-            sum.rays_march += a.rays_march; sum.node_visits += a.node_visits; sum.tri_tests += a.tri_tests; sum.box_tests += a.box_tests;
-            sum.ms_trace += a.ms_trace; sum.ms_shade += a.ms_shade; sum.trace_launches += a.trace_launches;
-            sum.blocks_rendered += a.blocks_rendered; sum.wave_node_steps += a.wave_node_steps; sum.wave_tri_steps += a.wave_tri_steps;
-            sum.wave_outer_steps += a.wave_outer_steps; sum.wave_lane_steps += a.wave_lane_steps; sum.wave_trans_steps += a.wave_trans_steps;
-            sum.trans_lanes += a.trans_lanes; sum.wave_uniform_node_steps += a.wave_uniform_node_steps; sum.queue_overflows += a.queue_overflows;
-            sum.rays_shadow_culled += a.rays_shadow_culled;
-        }
+        for (const trr_stats& a : st) add_stats(sum, a);
         sum.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
         *stats_out = sum;
     }
     if (result == TRR_ERR_CANCELLED) return fail(ctx, result, "render cancelled");
+    return TRR_OK;
+}
+
+static void add_stats(trr_stats& sum, const trr_stats& a) {
+    sum.rays_primary += a.rays_primary; sum.rays_shadow += a.rays_shadow; sum.rays_reflection += a.rays_reflection;
+    sum.rays_march += a.rays_march; sum.node_visits += a.node_visits; sum.tri_tests += a.tri_tests; sum.box_tests += a.box_tests;
+    sum.ms_trace += a.ms_trace; sum.ms_shade += a.ms_shade; sum.trace_launches += a.trace_launches;
+    sum.blocks_rendered += a.blocks_rendered; sum.wave_node_steps += a.wave_node_steps; sum.wave_tri_steps += a.wave_tri_steps;
+    sum.wave_outer_steps += a.wave_outer_steps; sum.wave_lane_steps += a.wave_lane_steps; sum.wave_trans_steps += a.wave_trans_steps;
+    sum.trans_lanes += a.trans_lanes; sum.wave_uniform_node_steps += a.wave_uniform_node_steps; sum.queue_overflows += a.queue_overflows;
+    sum.rays_shadow_culled += a.rays_shadow_culled;
+}
+
+// trr_render_blocks on several devices: the reference's sink sees blocks as they finish, in whatever order its worker threads
+// finish them (render.rs:109-113 `par_bridge`, :151-186).  Every device renders its blocks (block id % N == device index) in
+// batches on a host thread of its own; a finished batch is read back into that device's pinned strip copy and announced on a
+// queue, which the CALLING thread drains in arrival order: `sink` runs once per block, on the calling thread only, while the
+// devices go on rendering.  No gather and no assembly: the blocks go to the host anyway.  `progress` runs on the calling
+// thread too, after each delivered batch.  A cancel ends every device's loop at its next batch; blocks that were announced
+// before are still delivered (they are final), the batches in flight are dropped (render.rs:154).
+static int multi_render_blocks(trr_ctx* ctx, trr_scene* scene, float delta, uint32_t max_depth, uint32_t flags, uint32_t blocks_per_batch,
+                               const volatile int32_t* cancel_flag, trr_block_cb sink, trr_progress_cb progress, void* user, trr_stats* stats_out) {
+    if (scene->ctx != ctx || scene->replicas.size() != ctx->subs.size()) return fail(ctx, TRR_ERR_INVALID, "render: scene belongs to another context");
+    const uint32_t n = (uint32_t)ctx->subs.size();
+    const uint32_t w = scene->camera.width, h = scene->camera.height;
+    Tiling t;
+    if (!tiling_of(w, h, &t)) return fail(ctx, TRR_ERR_RESOLUTION, "trr_render_blocks: width and height must be >= 20 (render.rs:109)");
+    const auto wall0 = std::chrono::steady_clock::now();
+    const size_t sb = trr_strip_bytes(w, h, n), block_bytes = (size_t)t.bw * t.bh * 3;
+    // a row of the block grid per round of batches by default, split over the devices
+    const uint32_t per_frame = blocks_per_batch ? blocks_per_batch : t.nbx;
+    const uint32_t per_device = std::max(1u, (std::min(per_frame, t.nblocks) + n - 1) / n);
+    int rc;
+    std::vector<int> stage_slot(n, -1);
+    for (uint32_t d = 0; d < n; ++d) {
+        trr_ctx* c = ctx->subs[d];
+        HIPCHK(ctx, hipSetDevice(c->device));
+        if ((rc = ensure(c, c->strip, sb)) || (rc = acquire_pinned(c, sb, &stage_slot[d]))) {
+            for (uint32_t k = 0; k < d; ++k) ctx->subs[k]->pinned[stage_slot[k]].in_use = false;
+            return fail(ctx, rc, c->err);
+        }
+    }
+    struct Item { uint32_t dev, first, count; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Item> queue;
+    uint32_t running = n;
+    std::vector<trr_stats> st(n);
+    std::vector<int> res(n, TRR_OK);
+    auto render_one = [&](uint32_t d) {
+        trr_ctx* c = ctx->subs[d];
+        if (hipSetDevice(c->device) != hipSuccess) res[d] = fail(c, TRR_ERR_DEVICE, "hipSetDevice failed");
+        else {
+            uint8_t* stage = static_cast<uint8_t*>(c->pinned[stage_slot[d]].p);
+            BatchHook hook;
+            hook.blocks_per_batch = per_device;
+            hook.after_batch = [&, c, d, stage](uint32_t first, uint32_t count, hipStream_t s_) -> int {
+                hipError_t e = hipMemcpyAsync(stage + (size_t)first * block_bytes, (const uint8_t*)c->strip.p + (size_t)first * block_bytes,
+                                              (size_t)count * block_bytes, hipMemcpyDeviceToHost, s_);
+                if (e == hipSuccess) e = hipStreamSynchronize(s_);
+                if (e != hipSuccess) return fail(c, TRR_ERR_DEVICE, std::string("trr_render_blocks: block read-back: ") + hipGetErrorString(e));
+                { std::lock_guard<std::mutex> lock(mu); queue.push_back(Item{d, first, count}); }
+                cv.notify_one();
+                return TRR_OK;
+            };
+            res[d] = render_shard_impl(c, scene->replicas[d], delta, max_depth, flags, d, n, (uint8_t*)c->strip.p, sb, c->stream, nullptr, nullptr,
+                                       cancel_flag, nullptr, nullptr, stats_out ? &st[d] : nullptr, &hook);
+        }
+        { std::lock_guard<std::mutex> lock(mu); --running; }
+        cv.notify_one();
+    };
+    std::vector<std::thread> th;
+    for (uint32_t d = 0; d < n; ++d) th.emplace_back(render_one, d);
+    // the calling thread: hand over what has been announced, in arrival order, until every device's loop has ended
+    uint32_t delivered = 0;
+    size_t next = 0;
+    for (;;) {
+        Item it;
+        {
+            std::unique_lock<std::mutex> lock(mu);
+            cv.wait(lock, [&] { return next < queue.size() || running == 0; });
+            if (next >= queue.size()) break;   // running == 0 and nothing left
+            it = queue[next++];
+        }
+        const uint8_t* stage = static_cast<const uint8_t*>(ctx->subs[it.dev]->pinned[stage_slot[it.dev]].p);
+        for (uint32_t j = 0; j < it.count; ++j) {
+            const uint32_t b = it.dev + (it.first + j) * n;   // the device's (first + j)-th owned block
+            sink(user, b % t.nbx, b / t.nbx, t.bw, t.bh, stage + (size_t)(it.first + j) * block_bytes);
+        }
+        delivered += it.count;
+        if (progress) progress(user, delivered, t.nblocks);
+    }
+    for (auto& x : th) x.join();
+    for (uint32_t d = 0; d < n; ++d) ctx->subs[d]->pinned[stage_slot[d]].in_use = false;
+    int result = TRR_OK;
+    std::string msg;
+    for (uint32_t d = 0; d < n; ++d) {
+        if (res[d] == TRR_ERR_CANCELLED && result == TRR_OK) result = TRR_ERR_CANCELLED;
+        else if (res[d] != TRR_OK && res[d] != TRR_ERR_CANCELLED) {
+            result = res[d];
+            msg += (msg.empty() ? "device " : "; device ") + std::to_string(ctx->subs[d]->device) + ": " + ctx->subs[d]->err;
+        }
+    }
+    if (stats_out) {
+        trr_stats sum{};
+        for (const trr_stats& a : st) add_stats(sum, a);
+        sum.blocks_rendered = delivered;
+        sum.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        *stats_out = sum;
+    }
+    if (result == TRR_ERR_CANCELLED) return fail(ctx, result, "render cancelled");
+    if (result != TRR_OK) return fail(ctx, result, msg);
     return TRR_OK;
 }
 

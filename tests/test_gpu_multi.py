@@ -100,3 +100,85 @@ def test_n_device_logic_rehearsed_on_one_gpu(monkeypatch, n):
         rt.close()
     finally:
         multi.close()
+
+
+def test_blocks_of_a_multi_device_context_arrive_while_the_devices_still_render(monkeypatch):
+    """trr_render_blocks on a context of several devices (rehearsed with three sub-contexts on the one GPU): every device's host
+    thread announces its finished batches, the calling thread hands the blocks to the sink in ARRIVAL order (the reference's
+    `par_bridge` has no order either, render.rs:109-113) -- each block exactly once, the first one long before the frame is
+    done, the bytes those of the plain context."""
+    import ctypes as C
+    import time
+    sc = standin.parity_scene(1280, 720, detail=14)
+    sc.settings.anti_aliasing, sc.settings.samples, sc.settings.seed = True, 4, 5
+    plain = Context(0)
+    rt = Raytracer(sc, max_depth=4, context=plain)
+    want = rt.render_frame()["rgb"]
+    rt.close()
+    plain.close()
+    monkeypatch.setenv("TRR_MULTI_ALLOW_DUPLICATES", "1")
+    multi = Context(devices=[0, 0, 0])
+    try:
+        rt = Raytracer(sc, max_depth=4, context=multi)
+        rt.render_blocks(lambda xb, yb, blk: None)   # warm-up: work buffers, pinned staging
+        bh, bw = 720 // 20, 1280 // 20
+        for bpb in (0, 7, 400):
+            blocks, times, prog = {}, [], []
+            t0 = time.perf_counter()
+
+            def sink(xb, yb, blk):
+                assert (xb, yb) not in blocks
+                blocks[(xb, yb)] = blk.copy()
+                times.append(time.perf_counter() - t0)
+
+            out = rt.render_blocks(sink, blocks_per_batch=bpb, progress=lambda done, total: prog.append((done, total)))
+            t_end = time.perf_counter() - t0
+            assert not out["cancelled"] and len(blocks) == 400 and out["stats"].blocks_rendered == 400
+            for (xb, yb), blk in blocks.items():
+                assert np.array_equal(blk, want[yb * bh:(yb + 1) * bh, xb * bw:(xb + 1) * bw]), (bpb, xb, yb)
+            assert prog[-1] == (400, 400) and all(a[0] < b[0] for a, b in zip(prog, prog[1:]))
+            if bpb != 400:
+                # progressive: the first batch is handed over while most of the frame is still to be rendered
+                assert prog[0][0] < 100 and len(prog) >= 10, prog[:3]
+                assert times[0] < 0.5 * t_end, (times[0], t_end)
+        # a cancel raised from inside the sink: every device stops at its next batch; what had been announced is delivered
+        flag = C.c_int32(0)
+        seen = []
+
+        def cancelling_sink(xb, yb, blk):
+            seen.append((xb, yb))
+            flag.value = 1
+
+        out = rt.render_blocks(cancelling_sink, blocks_per_batch=20, cancel_flag=flag)
+        assert out["cancelled"] and 0 < len(seen) < 400 and len(set(seen)) == len(seen)
+        # the context is usable afterwards, and whole frames still go through the gather path
+        assert np.array_equal(rt.render_frame()["rgb"], want)
+        rt.close()
+    finally:
+        multi.close()
+
+
+@pytest.mark.parametrize("where", ["init", "gather"])
+def test_an_rccl_error_falls_back_to_peer_copies(monkeypatch, capfd, where):
+    """The RCCL path (ncclCommInitAll, grouped ncclGather) has never run between distinct devices; an error from either call must
+    cost a warning, not the frame: the strips are then exchanged by peer copies, for the rest of the context's life."""
+    sc = standin.parity_scene(320, 240, detail=10)
+    plain = Context(0)
+    rt = Raytracer(sc, max_depth=3, context=plain)
+    want = rt.render_frame()["rgb"]
+    rt.close()
+    plain.close()
+    monkeypatch.setenv("TRR_MULTI_FORCE_RCCL", "1")
+    monkeypatch.setenv("TRR_MULTI_INJECT_RCCL_FAILURE", where)
+    multi = Context(devices=[0])
+    try:
+        rt = Raytracer(sc, max_depth=3, context=multi)
+        assert np.array_equal(rt.render_frame()["rgb"], want)
+        err = capfd.readouterr().err
+        assert "exchanging the strips by peer copies" in err and ("ncclCommInitAll" if where == "init" else "ncclGather") in err
+        monkeypatch.delenv("TRR_MULTI_INJECT_RCCL_FAILURE")
+        assert np.array_equal(rt.render_frame()["rgb"], want)   # stays on peer copies: no second attempt, no second warning
+        assert "peer copies" not in capfd.readouterr().err
+        rt.close()
+    finally:
+        multi.close()

@@ -17,8 +17,10 @@ def _both(rt, shard, n_shards):
     a = torch.full((sb,), 7, dtype=torch.uint8, device="cuda")
     b = torch.full((sb,), 9, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()   # the library renders on its own (non-blocking) stream
+    free0 = torch.cuda.mem_get_info()[0]   # hipMemGetInfo: what the DEVICE has free, whoever allocates
     rt.render_shard_device_noalloc(shard, n_shards, a.data_ptr(), sb)
     rt.ctx.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0, "the entry point that allocates nothing changed the device's free memory"
     rt.render_shard_device(shard, n_shards, b.data_ptr(), sb)
     rt.ctx.synchronize()
     return a.cpu().numpy(), b.cpu().numpy()
@@ -43,6 +45,22 @@ def test_noalloc_entry_point_matches_render_shard_device():
         # and the whole small frame on the same context
         a2, b2 = _both(rt, 0, 1)
         assert np.array_equal(a2, b2)
+        # two callers on different streams and a second context of the same GPU share the one array: the per-device event
+        # makes them queue up on the device instead of racing (no host synchronisation between the calls here)
+        import torch
+        ctx2 = Context(0)
+        rt2 = Raytracer(small, max_depth=2, context=ctx2)
+        sb = rt.strip_bytes(1)
+        outs = [torch.zeros(sb, dtype=torch.uint8, device="cuda") for _ in range(6)]
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            (rt if k % 2 == 0 else rt2).render_shard_device_noalloc(0, 1, o.data_ptr(), sb, stream=streams[k % 3].cuda_stream)
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            assert np.array_equal(o.cpu().numpy(), b2), f"overlapping no-alloc call {k} differs"
+        rt2.close()
+        ctx2.close()
         rt.close()
         # a frame whose single block exceeds the static array is refused with the figures in the message
         huge = standin.parity_scene(3840, 2160, detail=4)
