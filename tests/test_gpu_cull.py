@@ -146,3 +146,22 @@ def test_cull_on_the_million_triangle_car_with_aa(ctx):
     got = _render(ctx, sc, 5, want_ids=False)
     assert want["rgb"].any() and np.array_equal(got["rgb"], want["rgb"])
     assert got["stats"].rays_shadow_culled > 0.05 * got["stats"].rays_shadow
+
+
+def test_known_divergence_once_a_colour_has_overflowed(ctx, oracle_mod):
+    """The cull's one assumption, pinned: it is exact while every colour is finite.  tests/test_oracle_kat.py::overflow_scene
+    drives the running colour to +inf next to a 3e38 light; at the light behind the wall the reference then computes
+    inf * 0.0 = NaN (mod.rs:178) and writes 0, while the cull -- which never traces that light's shadow ray -- keeps inf and
+    writes 255.  With TRR_CULL=0 the GPU follows the reference into the NaN."""
+    from tests.test_oracle_kat import overflow_scene
+    sc = overflow_scene(True, 60, 60)
+    ref = oracle_mod.OracleScene(sc).render(shade=oracle_mod.SHADE_HOISTED, max_depth=2, want_f32=True)
+    nan_px = np.isnan(ref["rgb_f32"]).all(axis=-1)
+    assert nan_px.any() and not nan_px.all() and (ref["rgb"][nan_px] == 0).all()
+    for schedule in ("levels", "persistent"):
+        off = _render(ctx, sc, 2, env={"TRR_SCHEDULE": schedule, "TRR_CULL": "0"})
+        assert np.array_equal(off["rgb"], ref["rgb"]), schedule
+        on = _render(ctx, sc, 2, env={"TRR_SCHEDULE": schedule})
+        assert on["stats"].rays_shadow_culled > 0
+        assert np.array_equal(on["rgb"][~nan_px], ref["rgb"][~nan_px]), schedule      # finite colours: exact
+        assert (on["rgb"][nan_px] == 255).all(), schedule                              # the divergence: inf kept, NaN never formed

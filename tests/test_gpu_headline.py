@@ -61,6 +61,30 @@ def test_config4_terrain_1m_triangles_on_a_block_sample(ctx, oracle_mod):
     _block_sample_parity(ctx, oracle_mod, sc, 5, 3, 16, "config 4 at 1 M triangles")
 
 
+def test_config4_terrain_at_its_full_10m_triangles(ctx, oracle_mod):
+    """BASELINE.json configs[3] at its stated size: the 10.0 M-triangle terrain (1.6 GB of nodes and triangles -- the one
+    configuration that does not fit the 256 MB Infinity Cache), 3840x2160, 1 spp, max_depth 5.  The whole frame from the
+    host-built (SAH) and the device-built (LBVH) tree must be the same bytes (the candidate-set invariant of DESIGN.md 2 at
+    full size), and the blocks 5::25 (16 of the 400) equal the oracle's, which builds its own one-triangle-leaf tree."""
+    import torch
+    sc = standin.standin_terrain(3840, 2160)
+    assert sc.triangle_count() >= 9_990_000
+    frames = {}
+    for build in ("host", "device"):
+        rt = Raytracer(sc, max_depth=5, context=ctx, build=build)
+        sb = rt.strip_bytes(1)
+        strip = torch.zeros(sb, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        rt.render_shard_device(0, 1, strip.data_ptr(), sb)
+        rt.ctx.synchronize()
+        frames[build] = strip.cpu().numpy()
+        rt.close()
+    assert frames["host"].any()
+    assert np.array_equal(frames["host"], frames["device"]), "10 M triangles: host-built and device-built trees render different bytes"
+    exact = _block_sample_parity(ctx, oracle_mod, sc, 5, 5, 25, "config 4 at 10 M triangles")
+    assert exact >= 0.999
+
+
 def test_config5_mirrors_depth8_at_4k_on_a_block_sample(ctx, oracle_mod):
     """BASELINE.json configs[4]: mirror spheres under an image sky, 4K, max_depth 9 (reflection depth 8); blocks 11::25.  The
     sky look-up goes through atan2f / asinf (ocml on the GPU, glibc in the oracle): single-LSB differences at texel borders."""

@@ -103,3 +103,42 @@ def test_cpp_cli_over_a_multi_device_context_renders_the_same_frame(scene_dir, t
         assert p.returncode == 0, p.stdout + p.stderr
         out[name] = load_image_rgb8(png)
     assert out["plain"].any() and np.array_equal(out["plain"], out["multi"])
+
+
+def test_tiff_and_jpeg_textures_and_an_exr_sky_reach_the_pixels(tmp_path, oracle_mod):
+    """The decoders of include/trayracer_image.hpp on the GPU path: a scene whose textures are an LZW TIFF and a baseline JPEG
+    (the formats of res/test/textures/) and whose sky is a PIZ OpenEXR (the format of res/skyboxes/, written by
+    tests/exr_writer.py) -- loaded by the Python loader (Pillow for TIFF / JPEG, the C++ decoder for EXR), rendered on the GPU
+    and compared with the oracle on the same loaded scene; then the same files through examples/trr_cli, whose every image
+    goes through the C++ decoders.  JPEG is the one lossy step: the two loaders' texels may differ by an LSB (measured:
+    equal), so the two frames are compared at the 1-LSB bar."""
+    import subprocess
+    src = standin.parity_scene(200, 150, detail=10)
+    # a second textured material, so that TIFF and JPEG both carry pixels of the frame
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:64, 0:96]
+    tex2 = np.stack([(xx * 3 + yy) % 256, (xx + yy * 5) % 256, (xx ^ yy) * 2 % 256], axis=-1).astype(np.uint8)
+    tex2 = np.clip(tex2.astype(np.int16) + rng.integers(-6, 7, tex2.shape), 0, 255).astype(np.uint8)
+    src.objects[2].materials[0].diffuse_texture = tex2
+    path = export_scene(src, str(tmp_path), tex_formats=("tif", "jpg"), sky_format="exr")
+    names = sorted(os.listdir(str(tmp_path)))
+    assert any(n.endswith(".tif") for n in names) and any(n.endswith(".jpg") for n in names) and "sky.exr" in names
+    sc = load_scene(path)
+    assert sc.settings.skybox.image is not None and np.array_equal(sc.settings.skybox.image, src.settings.skybox.image)   # HALF holds k / 255 well enough
+    textured = [m for o in sc.objects for m in o.materials if m.diffuse_texture is not None]
+    assert len(textured) == 2
+    rt = Raytracer(sc, max_depth=4)
+    try:
+        out = rt.render_frame(want_ids=True)
+    finally:
+        rt.close()
+    osc = oracle_mod.OracleScene(sc)
+    ref = osc.render(shade=oracle_mod.SHADE_HOISTED, max_depth=4)
+    osc.close()
+    assert_parity(out, ref, what="scene with TIFF / JPEG textures and an EXR sky")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "trr_cli")
+    png = os.path.join(str(tmp_path), "cpp.png")
+    p = subprocess.run([exe, path, "-o", png, "--max-depth", "4"], capture_output=True, text=True, timeout=100)
+    assert p.returncode == 0, p.stdout + p.stderr
+    d = np.abs(load_image_rgb8(png).astype(np.int16) - out["rgb"].astype(np.int16)).max(axis=-1)
+    assert (d <= 1).mean() >= 0.999, f"C++ loader + decoders: within 1 LSB on only {(d <= 1).mean():.6f} (exact {(d == 0).mean():.6f})"

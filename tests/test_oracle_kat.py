@@ -373,3 +373,34 @@ def test_golden_anti_aliasing(oracle_mod):
     # thread count must not change the image (the reference's rayon sum order does; ours is fixed, i ascending)
     r8 = oracle_mod.OracleScene(scene_from_arrays(g)).render(shade=oracle_mod.SHADE_LITERAL, max_depth=2, want_ids=False, threads=8)
     assert np.array_equal(r8["rgb"], g["rgb"])
+
+
+# ---- raytracer/mod.rs:162-178 when the running colour has overflowed: the edge of the GPU path's shadow-ray cull --------------
+def overflow_scene(with_dark_light=True, w=40, h=40):
+    """A wall facing the camera at z = -4 (illum 1: no specular term), light 0 a tenth of a unit in front of its centre with
+    intensity 3e38, light 1 BEHIND the wall (dot(L, N) < 0 on it) with a blocker between the wall and that light."""
+    wall = [((-4, -4, -4), (4, -4, -4), (4, 4, -4)), ((-4, -4, -4), (4, 4, -4), (-4, 4, -4))]
+    blocker = [((-4, -4, -5), (4, -4, -5), (4, 4, -5)), ((-4, -4, -5), (4, 4, -5), (-4, 4, -5))]
+    obj = Object(triangles=tri_rows(*wall, *blocker), material_index=np.array([0, 0, 1, 1], np.int32),
+                 materials=[mat(kd=(0.5, 0.5, 0.5), illum=1), mat(kd=(0.5, 0.5, 0.5), illum=1, dissolve=0.5)])
+    lights = [Light(np.array([0, 0, -3.9], F32), np.array([1, 1, 1], F32), 3.0e38)]
+    if with_dark_light:
+        lights.append(Light(np.array([0, 0, -6], F32), np.array([1, 1, 1], F32), 1.0))
+    return Scene(objects=[obj], lights=lights, camera=front_camera(w, h), settings=Settings())
+
+
+def test_a_colour_that_overflowed_turns_nan_at_a_light_that_adds_nothing(oracle_mod):
+    """mod.rs:176-178 at the wall's centre P = (0, 0, -4), N = +z.  Light 0: |Lp - P|^2 = 0.01 (fp32: 0.1^2 rounded), so
+    li = 3e38 / 0.01 overflows to +inf, di = max(L.N, 0) * li = inf and the colour becomes inf.  Light 1 is behind the wall:
+    di = max(-1, 0) * (1 / 4) = 0.0 exactly.  Its shadow ray finds the blocker, so the transmission is colour * Kd * dissolve =
+    inf (mod.rs:162-166), |T| = inf is not < 0.01 (mod.rs:171), and mod.rs:178 adds diffuse * T * 0.0 = inf * 0 = NaN: the pixel is
+    NaN, which `as u8` turns into 0 (render.rs:136-138).  Without light 1 the pixel is inf -> 255.  (The GPU path's shadow-ray
+    cull skips light 1 -- its ray cannot matter while every colour is finite -- and so keeps inf -> 255 here: the one place where
+    it leaves the reference's arithmetic, tests/test_gpu_cull.py.)"""
+    r = oracle_mod.OracleScene(overflow_scene(True)).render(threads=1, want_f32=True, max_depth=2)
+    assert np.isnan(r["rgb_f32"][20, 20]).all() and (r["rgb"][20, 20] == 0).all()
+    r1 = oracle_mod.OracleScene(overflow_scene(False)).render(threads=1, want_f32=True, max_depth=2)
+    assert np.isinf(r1["rgb_f32"][20, 20]).all() and (r1["rgb"][20, 20] == 255).all()
+    # away from the hot spot the colour stays finite and light 1 changes nothing
+    finite = np.isfinite(r1["rgb_f32"]).all(axis=-1)
+    assert finite.any() and np.array_equal(r["rgb"][finite], r1["rgb"][finite])
