@@ -267,7 +267,11 @@ def main():
                                     "their light adds exactly nothing at the hit (DESIGN.md 4, same image bit for bit)",
                        "mrays_algorithm_per_s": round(frame_rays * args.steps / elapsed / 1e6, 2) if elapsed > 0 else 0.0,
                        "scene_upload_s": round(upload_s, 2), "bvh_build": args.build,
-                       "frames_in_flight": args.frames_in_flight},
+                       "frames_in_flight": args.frames_in_flight,
+                       # HIP hardware queues the library planned its streams for (this script asks for 16 before HIP starts; the
+                       # box's own default is 4, with which frames of <= 2^26 samples lose the split schedule -- the headline
+                       # frame is above that limit and does not use it either way)
+                       "gpu_max_hw_queues": int(N.lib().trr_hw_queues())},
             "pipelined": pipelined, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

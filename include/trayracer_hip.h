@@ -133,6 +133,8 @@ typedef struct trr_stats {
     uint64_t rays_shadow_culled;   /* of rays_shadow: answered without a traversal, because the light's diffuse and specular
                                     * intensities at the hit are exactly 0.0 and the material is no mirror -- whatever the ray
                                     * found, mod.rs:171-196 would add exactly nothing */
+    uint64_t rays_primary_culled;  /* of rays_primary: camera rays answered "no hit" (mod.rs:119) without a ray of their own, because
+                                    * no leaf box of the scene projects onto their 8x8-pixel tile */
 } trr_stats;
 
 typedef void (*trr_progress_cb)(void* user, uint32_t blocks_done, uint32_t blocks_total);
@@ -285,6 +287,10 @@ void trr_camera_ray(const trr_camera* camera, float x, float y, float origin[3],
 
 /* Library / device description for logs: "trayracer_hip <version> gfx950 ...". */
 const char* trr_version(void);
+/* The number of HIP hardware queues the library plans its streams for: the value of GPU_MAX_HW_QUEUES that the host had set
+ * when the library was loaded, else the 16 the library's initialiser sets itself (a frame uses up to nine streams; with HIP's
+ * default of 4 the library does not use its split schedule -- DESIGN.md section 4).  Measurements quote it. */
+int trr_hw_queues(void);
 
 #ifdef __cplusplus
 }

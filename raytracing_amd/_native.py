@@ -62,7 +62,7 @@ class Stats(C.Structure):
                 ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64), ("wave_outer_steps", C.c_uint64),
                 ("wave_lane_steps", C.c_uint64), ("wave_trans_steps", C.c_uint64), ("trans_lanes", C.c_uint64),
                 ("wave_uniform_node_steps", C.c_uint64), ("queue_overflows", C.c_uint64),
-                ("rays_shadow_culled", C.c_uint64)]
+                ("rays_shadow_culled", C.c_uint64), ("rays_primary_culled", C.c_uint64)]
 
     def rays(self) -> int:
         return self.rays_primary + self.rays_shadow + self.rays_reflection + self.rays_march
@@ -91,7 +91,7 @@ EXPORTS = [
     "trr_create", "trr_create_multi", "trr_device_count", "trr_shard_blocks", "trr_destroy", "trr_last_error", "trr_scene_create", "trr_scene_create_ex", "trr_scene_get_info",
     "trr_scene_validate", "trr_scene_destroy", "trr_scene_set_instances",
     "trr_scene_set_lights", "trr_scene_set_settings", "trr_scene_set_camera", "trr_render", "trr_render_blocks", "trr_render_shard_device",
-    "trr_strip_bytes", "trr_render_shard_device_noalloc", "trr_noalloc_scratch_bytes", "trr_assemble_device", "trr_synchronize", "trr_collect_stats", "trr_object_matrices", "trr_camera_ray", "trr_version",
+    "trr_strip_bytes", "trr_render_shard_device_noalloc", "trr_noalloc_scratch_bytes", "trr_assemble_device", "trr_synchronize", "trr_collect_stats", "trr_object_matrices", "trr_camera_ray", "trr_version", "trr_hw_queues",
 ]
 
 
@@ -124,6 +124,7 @@ def lib() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
     L.trr_version.restype = C.c_char_p
+    L.trr_hw_queues.restype = C.c_int
     L.trr_last_error.restype = C.c_char_p
     L.trr_last_error.argtypes = [vp]
     L.trr_create.restype = i32

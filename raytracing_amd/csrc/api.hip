@@ -76,6 +76,7 @@ struct trr_ctx {
     // of one batch drain (few long rays left) while the next batch's kernels fill the freed CUs.
     struct WorkSet {
         DevBuf hits, level, term, nlev, color, occ, wqueue, gqueue, shadow_q, shadow_deep[2], chain_q[2], counters, spill;
+        DevBuf groups;                             // camera-ray cull: the batch's traced 64-sample groups (kernels.hip: k_cover_groups)
         hipStream_t stream = nullptr;
         hipStream_t aux[2] = {nullptr, nullptr};   // split schedule: level 0's shadow rays / the deeper levels' shadow rays
         std::vector<hipEvent_t> sync_ev;           // split schedule: [2 l] level l set up, [2 l + 1] level l's shadow rays traced
@@ -85,6 +86,15 @@ struct trr_ctx {
     WorkSet ws[MAX_LANES];
     hipEvent_t fork = nullptr;
     DevBuf strip, frame, ids_obj, ids_tri;
+    // camera-ray cull: the tile mask of a FRAME (kernels.hip: k_cover_boxes), made once on the caller's stream before the
+    // frame's batches fork.  Two sets taken in turn, each with an event that its last user records when the frame's work has
+    // joined the caller's stream again and that the next user waits for: frames in flight on different streams do not share one.
+    struct CoverSet {
+        DevBuf mask, big, words;   // words: [0] give-up flag, [1] big rectangles
+        hipEvent_t free_ev = nullptr;
+    };
+    CoverSet cover[2];
+    uint32_t cover_turn = 0;
     std::vector<hipEvent_t> events;
     int bpc[2] = {0, 0};                 // resident 256-thread blocks per CU of k_trace<COUNT> (occupancy query, once)
     int bpc_level[2][2] = {{0, 0}, {0, 0}};   // ... of k_trace_level<RAYGEN, COUNT>
@@ -140,9 +150,14 @@ struct trr_scene {
     int device = 0;                      // ctx->device, kept so that trr_scene_destroy does not touch the context
     std::vector<trr_scene*> replicas;    // scene of a multi-device context: one uploaded copy per device, nothing else
     DevBuf nodes, qnodes, tris, interp, objs, mats, texs, texels, lights, sky;
+    DevBuf node_begin;                   // [n_objs + 1] first node of every object (camera-ray cull)
+    DevBuf cover_boxes;                  // camera-ray cull: boxes that hold every triangle's own box (launch.h: CoverBox)
+    uint32_t n_cover = 0;
+    bool cover_ok = false;               // the cover boxes exist (every object's root is an inner node or empty)
     bool quantised = false;              // qnodes holds the 64-B form of every node (kernels.hip: k_quantise_nodes)
     bool any_reflective = true;          // some material is a mirror (illum 3 / 4, material.rs:47-49): reflection rays can exist
     std::vector<ObjRec> h_objs;
+    std::vector<uint32_t> h_node_begin;  // host copy of node_begin
     uint32_t n_objs = 0, n_lights = 0, n_mats = 0, n_tex = 0;
     uint64_t n_nodes = 0, n_tris_total = 0, n_tris_live = 0;
     uint32_t bvh_depth = 0;
@@ -221,6 +236,8 @@ static void add_stats(trr_stats& sum, const trr_stats& a);
 // ---- extern "C" ---------------------------------------------------------------------------------------------
 extern "C" {
 
+int trr_hw_queues(void) { return g_hw_queues; }
+
 const char* trr_version(void) { return "trayracer_hip 0.1 (gfx950, wavefront BVH4 tracer)"; }
 
 const char* trr_last_error(const trr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_tls_error.c_str(); }
@@ -262,7 +279,9 @@ int trr_create(int device_id, trr_ctx** out) {
             return fail(nullptr, TRR_ERR_DEVICE, "hipStreamCreate / hipEventCreate for a work set failed");
         }
     }
-    if (hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->cover[0].free_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->cover[1].free_ev, hipEventDisableTiming) != hipSuccess) {
         trr_destroy(ctx);
         return fail(nullptr, TRR_ERR_DEVICE, "hipEventCreate failed");
     }
@@ -297,7 +316,7 @@ void trr_destroy(trr_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (auto& w : ctx->ws) {
         for (DevBuf* b : {&w.hits, &w.level, &w.term, &w.nlev, &w.color, &w.occ, &w.wqueue, &w.gqueue, &w.shadow_q, &w.shadow_deep[0], &w.shadow_deep[1],
-                          &w.chain_q[0], &w.chain_q[1], &w.counters, &w.spill})
+                          &w.chain_q[0], &w.chain_q[1], &w.counters, &w.spill, &w.groups})
             release(*b);
         for (hipEvent_t ev : w.sync_ev) (void)hipEventDestroy(ev);
         if (w.done) (void)hipEventDestroy(w.done);
@@ -305,6 +324,10 @@ void trr_destroy(trr_ctx* ctx) {
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     if (ctx->fork) (void)hipEventDestroy(ctx->fork);
+    for (auto& cs : ctx->cover) {
+        for (DevBuf* b : {&cs.mask, &cs.big, &cs.words}) release(*b);
+        if (cs.free_ev) (void)hipEventDestroy(cs.free_ev);
+    }
     for (DevBuf* b : {&ctx->strip, &ctx->frame, &ctx->ids_obj, &ctx->ids_tri}) release(*b);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     for (auto& pn : ctx->pinned)
@@ -496,6 +519,7 @@ static int build_scene_device(trr_ctx* ctx, trr_scene* sc, const trr_object_desc
     uint64_t node_base = 0, slot_base = 0, interp_base = 0;
     uint32_t depth_max = 0, stack_max = 0;
     sc->h_objs.assign(n_objects, ObjRec{});
+    sc->h_node_begin.clear();
     for (uint32_t oi = 0; oi < n_objects; ++oi) {
         const trr_object_desc& d = objects[oi];
         // leaf references hold the first triangle slot in 29 bits (see trr_scene_create_ex)
@@ -511,6 +535,7 @@ static int build_scene_device(trr_ctx* ctx, trr_scene* sc, const trr_object_desc
             free_parts();
             return fail(ctx, e == hipErrorOutOfMemory ? TRR_ERR_NOMEM : TRR_ERR_DEVICE, "device BVH build of object " + std::to_string(oi) + ": " + msg);
         }
+        sc->h_node_begin.push_back((uint32_t)node_base);
         ObjRec& o = sc->h_objs[oi];
         fill_obj_matrices(o, d.transform, d.inverse);
         o.root = parts[oi].root_ref;
@@ -545,10 +570,53 @@ static int build_scene_device(trr_ctx* ctx, trr_scene* sc, const trr_object_desc
     if (std::getenv("TRR_DEBUG")) std::fprintf(stderr, "[trr build] packed %llu nodes, %llu triangles\n", (unsigned long long)node_base, (unsigned long long)slot_base);
     if (e != hipSuccess) return fail(ctx, TRR_ERR_DEVICE, std::string("device BVH build: packing the objects: ") + hipGetErrorString(e));
     sc->n_nodes = node_base;
+    sc->h_node_begin.push_back((uint32_t)node_base);
     sc->n_tris_live = slot_base;
     sc->bvh_depth = depth_max;
     sc->stack_need = stack_max;
     return TRR_OK;
+}
+
+// Camera-ray cull: the scene's cover boxes (launch.h), made on the device from the packed node array of either builder.  Top
+// down from every object's root, one tree level per round: leaves met on the way become boxes, inner nodes go on to the next
+// round, until the next level would exceed the budget -- then every child box of the level's nodes is taken.  A few tiny
+// launches and two words read back per round, once per scene.
+static int build_cover_boxes(trr_ctx* ctx, trr_scene* sc) {
+    std::vector<uint32_t> frontier;
+    for (const ObjRec& o : sc->h_objs)
+        if (o.root != REF_EMPTY) frontier.push_back(o.root);   // (cover_ok: no root is a leaf)
+    sc->n_cover = 0;
+    int rc = ensure(ctx, sc->cover_boxes, (size_t)COVER_BOX_BUDGET * sizeof(CoverBox));
+    if (rc != TRR_OK || frontier.empty()) return rc;
+    DevBuf fr[2], cnt;
+    auto done = [&](int code) { release(fr[0]); release(fr[1]); release(cnt); return code; };
+    if ((rc = ensure(ctx, fr[0], (size_t)COVER_BOX_BUDGET * 4)) || (rc = ensure(ctx, fr[1], (size_t)COVER_BOX_BUDGET * 4)) || (rc = ensure(ctx, cnt, 256)))
+        return done(rc);
+    if (frontier.size() * 4 > COVER_BOX_BUDGET) { sc->cover_ok = false; return done(TRR_OK); }   // (thousands of objects: no cull)
+    hipError_t e = hipMemcpy(fr[0].p, frontier.data(), frontier.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(cnt.p, 0, 256);
+    uint32_t n_in = (uint32_t)frontier.size(), n_boxes = 0;
+    uint32_t* d_cnt = static_cast<uint32_t*>(cnt.p);   // [0] boxes so far, [1 + round % 2] next frontier
+    for (uint32_t round = 0; e == hipSuccess && n_in != 0; ++round) {
+        // the level below this one holds at most 4 n_in nodes with 16 n_in child boxes
+        const bool last = (uint64_t)n_boxes + 16ull * n_in > COVER_BOX_BUDGET || 4ull * n_in > COVER_BOX_BUDGET;
+        uint32_t* n_out = d_cnt + 1 + (round & 1u);
+        e = hipMemsetAsync(n_out, 0, 4, ctx->stream);
+        if (e != hipSuccess) break;
+        launch_cover_expand(ctx->stream, static_cast<const Node4*>(sc->nodes.p), static_cast<const uint32_t*>(sc->node_begin.p), sc->n_objs,
+                            static_cast<const uint32_t*>(fr[round & 1u].p), n_in, static_cast<uint32_t*>(fr[(round + 1) & 1u].p), n_out,
+                            static_cast<CoverBox*>(sc->cover_boxes.p), d_cnt, COVER_BOX_BUDGET, last);
+        uint32_t back[3] = {0, 0, 0};
+        e = hipMemcpyAsync(back, d_cnt, 12, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        n_boxes = back[0];
+        n_in = last ? 0u : back[1 + (round & 1u)];
+    }
+    if (e != hipSuccess) return done(fail(ctx, TRR_ERR_DEVICE, std::string("cover boxes: ") + hipGetErrorString(e)));
+    if (n_boxes > COVER_BOX_BUDGET) sc->cover_ok = false;   // cannot happen (the rounds stop before the budget); no cull rather than a partial list
+    sc->n_cover = std::min(n_boxes, COVER_BOX_BUDGET);
+    if (std::getenv("TRR_DEBUG")) std::fprintf(stderr, "[trr] camera-ray cull: %u cover boxes\n", sc->n_cover);
+    return done(TRR_OK);
 }
 
 int trr_scene_create(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_objects, const trr_image_rgb8* textures,
@@ -596,6 +664,7 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
         n_total += d.n_triangles;
     }
 
+    std::vector<uint32_t> node_begin_host;   // first node of every object (camera-ray cull)
     for (uint32_t oi = 0; build == TRR_BUILD_HOST && oi < n_objects; ++oi) {
         const trr_object_desc& d = objects[oi];
         const uint32_t nt = d.n_triangles;
@@ -668,6 +737,7 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
         BuildResult br;
         build_bvh4(live_boxes.data(), (uint32_t)live_boxes.size(), 0, &br);
         const uint32_t node_base = (uint32_t)nodes.size();
+        node_begin_host.push_back(node_base);
         const uint32_t slot_base = (uint32_t)tris.size();
         if ((uint64_t)slot_base + live_boxes.size() >= (1ull << 29))
             return fail(ctx, TRR_ERR_INVALID, "trr_scene_create: more than 2^29 triangles");
@@ -705,6 +775,8 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
     sc->device = ctx->device;
     sc->n_objs = n_objects;
     sc->h_objs = objs;
+    node_begin_host.push_back((uint32_t)nodes.size());
+    sc->h_node_begin = node_begin_host;
     sc->n_nodes = nodes.size();
     sc->n_tris_total = n_total;
     sc->n_tris_live = tris.size();
@@ -747,6 +819,14 @@ int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n
                                             " entries, the trace kernel holds " + std::to_string(TRACE_STACK_ENTRIES) +
                                             (build == TRR_BUILD_DEVICE ? " (build this scene with TRR_BUILD_HOST)" : ""));
     if (rc == TRR_OK) rc = upload(ctx, sc->objs, sc->h_objs.data(), sc->h_objs.size() * sizeof(ObjRec));
+    if (rc == TRR_OK) {
+        // camera-ray cull: usable when every leaf box of the scene is a child box of some node, i.e. no object's root is a leaf
+        // (an object of <= 4 triangles; of ONE triangle, the crate even skips the box test)
+        sc->cover_ok = n_objects != 0 && sc->h_node_begin.size() == (size_t)n_objects + 1;
+        for (const ObjRec& o : sc->h_objs) sc->cover_ok = sc->cover_ok && (o.root == REF_EMPTY || !(o.root & REF_LEAF)) && !(o.flags & 1u);
+        if (sc->cover_ok) rc = upload(ctx, sc->node_begin, sc->h_node_begin.data(), sc->h_node_begin.size() * sizeof(uint32_t));
+        if (rc == TRR_OK && sc->cover_ok) rc = build_cover_boxes(ctx, sc);
+    }
     if (rc == TRR_OK) rc = quantise_scene_nodes(ctx, sc);
     if (rc != TRR_OK) {
         trr_scene_destroy(sc);
@@ -856,7 +936,7 @@ void trr_scene_destroy(trr_scene* sc) {
     // memory of the device; destroying scenes first is still the documented order)
     (void)hipSetDevice(sc->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&sc->nodes, &sc->qnodes, &sc->tris, &sc->interp, &sc->objs, &sc->mats, &sc->texs, &sc->texels, &sc->lights, &sc->sky})
+    for (DevBuf* b : {&sc->nodes, &sc->qnodes, &sc->tris, &sc->interp, &sc->objs, &sc->mats, &sc->texs, &sc->texels, &sc->lights, &sc->sky, &sc->node_begin, &sc->cover_boxes})
         release(*b);
     delete sc;
 }
@@ -1001,7 +1081,10 @@ static hipEvent_t get_event(trr_ctx* ctx, size_t i) {
 // launch (work items claimed), [CW_NSHADOW + lvl] / [CW_NCHAIN + lvl] shadow rays emitted at / chain rays entering level
 // lvl (level-synchronous schedule), [CW_SPILL + k] entries spilled by launch k (persistent schedule); the 64-bit kernel
 // counters (device_types.h KC_*) follow at byte offset CW_WORDS*4.
-enum { CW_WORK = 0, CW_WORK_STRIDE = 8, CW_NSHADOW = 4160, CW_NCHAIN = 4448, CW_SPILL = 4736, CW_ZERO = 5024, CW_WORDS = 5120 };
+enum { CW_WORK = 0, CW_WORK_STRIDE = 8, CW_NSHADOW = 4160, CW_NCHAIN = 4448, CW_SPILL = 4736, CW_ZERO = 5024,
+       CW_NGROUPS = 5027,   // camera-ray cull: 64-sample groups of the batch that are traced
+       CW_WORDS = 5120 };
+static constexpr uint32_t COVER_BIG_CAP = 1u << 16;
 static constexpr uint32_t MAX_FOLLOWUPS = 7;
 static constexpr size_t RB_STRIDE = CW_WORDS * 4 + 8 * 16;   // per batch: launch / queue counters + up to 16 kernel counters
 static_assert(KC_COUNT <= 16, "kernel counters outgrew the read-back block");
@@ -1035,6 +1118,7 @@ static void finish_stats(trr_ctx* ctx, const trr_ctx::PendingStats& f) {
         stats->rays_reflection += k[KC_CHAIN_RAYS];
         stats->queue_overflows += k[KC_QUEUE_OVERFLOW];
         stats->rays_shadow_culled += k[KC_SHADOW_CULLED];
+        stats->rays_primary_culled += k[KC_PRIMARY_CULLED];
         stats->node_visits += k[KC_NODES]; stats->box_tests += k[KC_BOXES]; stats->tri_tests += k[KC_TRIS]; stats->rays_march += k[KC_MARCH];
         stats->wave_node_steps += k[KC_WNODE]; stats->wave_tri_steps += k[KC_WTRI]; stats->wave_outer_steps += k[KC_WOUTER];
         stats->wave_lane_steps += k[KC_WLANES]; stats->wave_trans_steps += k[KC_WTRANS]; stats->trans_lanes += k[KC_LTRANS];
@@ -1073,6 +1157,10 @@ struct WorkView {
     float4* chain_q[2] = {nullptr, nullptr};   // [cap] reflection rays entering the even / odd levels
     void* counters = nullptr;   // RB_STRIDE bytes: work counter + kernel counters
     uint2* spill = nullptr;
+    // camera-ray cull (nullptr: off)
+    const uint8_t* cover_mask = nullptr;   // the frame's tile mask
+    const uint32_t* cover_flags = nullptr; // the frame's give-up flag
+    uint32_t* groups = nullptr;
 };
 
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -1126,6 +1214,20 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
                         EvBegin&& ev_begin, EvEnd&& ev_end) {
     uint32_t* cw = (uint32_t*)w.counters;
     unsigned long long* kc = (unsigned long long*)((char*)w.counters + CW_WORDS * 4);
+    // ---- camera-ray cull: the batch's 64-sample groups that own a pixel of a tile the frame's mask marks ----
+    const bool camcull = w.cover_mask != nullptr && w.groups != nullptr && bp.n_samples != 0u;
+    if (camcull) {
+        CoverIO cio{};
+        cio.mask = const_cast<uint8_t*>(w.cover_mask);
+        cio.tiles_x = (fp.width + 7u) / 8u; cio.tiles_y = (fp.height + 7u) / 8u;
+        cio.flags = const_cast<uint32_t*>(w.cover_flags);
+        cio.groups = w.groups; cio.n_groups = cw + CW_NGROUPS;
+        cio.nlev = w.nlev;
+        cio.counters = kc;
+        ev_begin(1, s_);
+        launch_cover_groups(s_, fp, bp, cio);
+        ev_end(s_);
+    }
     if (g.schedule == SCHED_PERSISTENT) {
         TraceIO tio{};
         tio.hits = w.hits;
@@ -1140,6 +1242,7 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
         tio.counters = kc;
         tio.spill = w.spill;
         tio.cull = g.cull;
+        if (camcull) { tio.groups = w.groups; tio.n_groups = cw + CW_NGROUPS; }
         // Launch 0 takes the camera rays.  With follow-ups, a wavefront that can claim no more work items spills the rays
         // it would queue, and launch k >= 1 deals what launch k - 1 spilled evenly over all wavefronts (the last one spills
         // nothing; a chain is at most max_depth reflection rays long, so deeper follow-ups would find nothing).
@@ -1169,9 +1272,11 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
         tio.work_counter = cw + CW_WORK + 0;
         tio.first_obj = ids_obj_dev;
         tio.first_tri = ids_tri_dev;
+        if (camcull) { tio.groups = w.groups; tio.n_groups = cw + CW_NGROUPS; }
         ev_begin(0, s_);
         launch_trace_level(true, count, g.raygen, s_, fp, bp, tio);
         ev_end(s_);
+        tio.groups = nullptr; tio.n_groups = nullptr;   // (the secondary-ray launches copy this descriptor)
         const uint32_t n_levels = std::min(fp.max_depth, std::max(1u, g.levels));   // deeper levels would find empty queues
         if (g.split != 0u && n_levels >= 1u && w.aux[0] != nullptr && w.sync_ev != nullptr) {
             // ---- split schedule.  Only the reflection rays carry the chain on: level l + 1's hit set-up needs their hits
@@ -1479,6 +1584,9 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
                      ctx->bpc_level[1][cb], ctx->bpc_level[0][cb], lanes, (unsigned long long)want_batches);
     const uint32_t qcap = queue_capacity(L);
     int rc;
+    // camera-ray cull (kernels.hip: k_cover_*): whenever the scene's leaf boxes are all in its node array; TRR_CAMCULL=0 switches it off
+    bool camcull_on = sc->cover_ok && sc->cover_boxes.p != nullptr;
+    if (const char* e = std::getenv("TRR_CAMCULL")) camcull_on = camcull_on && e[0] != '0';
     // `pool` work sets may be used by this call: its `lanes` consecutive ones starting at lane_base.  A single-batch frame
     // of a pipelined caller (TRR_FLAG_PIPELINED) takes the two sets in turn, so that consecutive frames, queued on
     // different streams, overlap each other instead of two half-size batches of the same frame.
@@ -1495,6 +1603,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
             (rc = ensure(ctx, w.occ, (size_t)cap * 4 * std::max(1u, L) * D)) || (rc = ensure(ctx, w.counters, RB_STRIDE)) ||
             (rc = ensure(ctx, w.spill, trace_spill_bytes(trace_grid))))
             return rc;
+        if (camcull_on && (rc = ensure(ctx, w.groups, (size_t)(cap / 64 + 1) * 4))) return rc;
         if (schedule == SCHED_PERSISTENT) {
             if ((rc = ensure(ctx, w.wqueue, trace_queue_bytes(trace_grid, qcap))) ||
                 (rc = ensure(ctx, w.gqueue, grids.followups ? 2 * (size_t)spill_capacity(trace_grid, L) * 32 : 256)))
@@ -1556,6 +1665,35 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         if (result == TRR_OK || result == TRR_ERR_CANCELLED) result = fail(ctx, TRR_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e_));
         return false;
     };
+    // camera-ray cull: this frame's tile mask, on the caller's stream, before the batches fork from it
+    trr_ctx::CoverSet* cover_set = nullptr;
+    if (camcull_on) {
+        trr_ctx::CoverSet& cs = ctx->cover[ctx->cover_turn++ & 1u];
+        const uint32_t tiles_x = (tl.w + 7) / 8, tiles_y = (tl.h + 7) / 8;
+        if ((rc = ensure(ctx, cs.mask, (size_t)tiles_x * tiles_y)) || (rc = ensure(ctx, cs.big, (size_t)COVER_BIG_CAP * sizeof(uint4))) ||
+            (rc = ensure(ctx, cs.words, 256))) {
+            if (stats) ctx->pinned[pinned_slot].in_use = false;
+            return rc;
+        }
+        CoverIO cio{};
+        cio.mask = (uint8_t*)cs.mask.p; cio.tiles_x = tiles_x; cio.tiles_y = tiles_y;
+        cio.flags = (uint32_t*)cs.words.p;
+        cio.boxes = (const CoverBox*)sc->cover_boxes.p; cio.n_boxes = sc->n_cover;
+        // where the samples of pixel x lie (mod.rs:233-240, 251-252): at x exactly without anti-aliasing; else from x - 1/s to
+        // below x + 1, vertically to below y + (yi_max + 1)/s with yi_max = (samples - 1) / s; one more pixel on every side
+        const float sq = (float)std::max(1u, fp.sqrt_spp);
+        const float below = fp.aa ? 1.0f / sq : 0.0f, above_x = fp.aa ? 1.0f : 0.0f;
+        const float above_y = fp.aa ? (float)((fp.spp - 1u) / std::max(1u, fp.sqrt_spp) + 1u) / sq : 0.0f;
+        cio.pad_x_lo = above_x + 1.0f; cio.pad_x_hi = below + 1.0f;   // a box edge at px reaches the pixels x with x + above >= px, x - below <= px
+        cio.pad_y_lo = above_y + 1.0f; cio.pad_y_hi = below + 1.0f;
+        cio.big = (uint4*)cs.big.p; cio.n_big = (uint32_t*)cs.words.p + 1; cio.big_cap = COVER_BIG_CAP;
+        if (chk(hipStreamWaitEvent(st, cs.free_ev, 0), "hipStreamWaitEvent") &&
+            chk(hipMemsetAsync(cs.mask.p, 0, (size_t)tiles_x * tiles_y, st), "hipMemsetAsync") &&
+            chk(hipMemsetAsync(cs.words.p, 0, 256, st), "hipMemsetAsync")) {
+            launch_cover_mask(st, fp, cio);
+            cover_set = &cs;
+        }
+    }
     const bool forked = pool > 1;
     if (forked) {
         // every lane stream waits for what the caller's stream has queued so far (the strip clear) AND for the previous
@@ -1604,6 +1742,9 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         wv.shadow_deep[0] = (float4*)w.shadow_deep[0].p; wv.shadow_deep[1] = (float4*)w.shadow_deep[1].p;
         wv.aux[0] = w.aux[0]; wv.aux[1] = w.aux[1];
         wv.sync_ev = w.sync_ev.empty() ? nullptr : w.sync_ev.data();
+        if (cover_set) {
+            wv.cover_mask = (const uint8_t*)cover_set->mask.p; wv.cover_flags = (const uint32_t*)cover_set->words.p; wv.groups = (uint32_t*)w.groups.p;
+        }
         queue_batch(fp, bp, wv, grids, count, strip_dev, ids_obj_dev, ids_tri_dev, s_, ev_begin, ev_end);
         if (!chk(hipGetLastError(), "kernel launch")) break;
         if (stats && !chk(hipMemcpyAsync(pinned_base + rb_stride * bi, w.counters.p, rb_stride, hipMemcpyDeviceToHost, s_), "hipMemcpyAsync")) break;
@@ -1646,6 +1787,7 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
     } else {
         chk(hipEventRecord(ctx->ws[0].done, st), "hipEventRecord");
     }
+    if (cover_set) chk(hipEventRecord(cover_set->free_ev, st), "hipEventRecord");   // the mask's next user waits for this frame
     if (stats && result != TRR_OK && result != TRR_ERR_CANCELLED) {
         ctx->pinned[pinned_slot].in_use = false;   // a failed frame leaves no statistics pending
     } else if (stats) {
@@ -2146,6 +2288,7 @@ static void add_stats(trr_stats& sum, const trr_stats& a) {
     sum.wave_outer_steps += a.wave_outer_steps; sum.wave_lane_steps += a.wave_lane_steps; sum.wave_trans_steps += a.wave_trans_steps;
     sum.trans_lanes += a.trans_lanes; sum.wave_uniform_node_steps += a.wave_uniform_node_steps; sum.queue_overflows += a.queue_overflows;
     sum.rays_shadow_culled += a.rays_shadow_culled;
+    sum.rays_primary_culled += a.rays_primary_culled;
 }
 
 // trr_render_blocks on several devices: the reference's sink sees blocks as they finish, in whatever order its worker threads

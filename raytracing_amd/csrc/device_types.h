@@ -89,7 +89,7 @@ constexpr int LEVEL_F4 = 3;
 
 // 64-bit kernel counters of one batch (behind the work counter in the batch's counter block)
 enum { KC_NODES = 0, KC_BOXES, KC_TRIS, KC_MARCH, KC_WNODE, KC_WTRI, KC_WOUTER, KC_WLANES, KC_WTRANS, KC_LTRANS, KC_WUNI,
-       KC_SHADOW_RAYS, KC_CHAIN_RAYS, KC_QUEUE_OVERFLOW, KC_SHADOW_CULLED, KC_COUNT };
+       KC_SHADOW_RAYS, KC_CHAIN_RAYS, KC_QUEUE_OVERFLOW, KC_SHADOW_CULLED, KC_PRIMARY_CULLED, KC_COUNT };
 
 // Everything a kernel needs about the frame (passed by value).
 struct FrameParams {

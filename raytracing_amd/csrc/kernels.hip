@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
         // for free), instead of each wavefront finishing its own, very unequal, backlog.
         from_q = ca->io.src_q != nullptr;
         total = from_q ? min(*ca->io.src_n, ca->io.src_cap) + (ca->io.src_q2 ? min(*ca->io.src_n2, ca->io.src_cap2) : 0u)
-                       : ca->bp.n_samples;
+                       : (ca->io.groups != nullptr ? *ca->io.n_groups * 64u : ca->bp.n_samples);
         chunk_min = ca->io.chunk_min;
         claim = work_claim_init(total, gridDim.x * (TRACE_THREADS / 64), chunk_min);
     }
@@ -504,12 +504,14 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace(Trac
                                 start_secondary(idx < n1 ? io.src_q + (size_t)idx * 2u : io.src_q2 + (size_t)(idx - n1) * 2u);
                             }
                         }
-                    } else if (cur == REF_IDLE && rank >= take_q && rank - take_q < take) {
-                        const uint32_t pix = idx / fp.spp, si = idx - pix * fp.spp;
+                    } else if (cur == REF_IDLE && rank >= take_q && rank - take_q < take &&
+                               (io.groups == nullptr || io.groups[idx >> 6] * 64u + (idx & 63u) < bp.n_samples)) {
+                        const uint32_t sidx = io.groups == nullptr ? idx : io.groups[idx >> 6] * 64u + (idx & 63u);   // camera-ray cull
+                        const uint32_t pix = sidx / fp.spp, si = sidx - pix * fp.spp;
                         const PixelPos pp = pixel_of(fp, bp, pix);
                         ro = f3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
                         rd = primary_dir(fp, pp.x, pp.y, si);
-                        r_sample = idx;
+                        r_sample = sidx;
                         r_meta = 0u;           // chain ray of level 0
                         fl = F_FIRST;
                         obj_i = 0xFFFFFFFFu;
@@ -912,7 +914,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
     const float delta = fp.delta;
 
     uint32_t n_shadow = 0, total;
-    if (RAYGEN) total = bp.n_samples;
+    if (RAYGEN) total = io.groups != nullptr ? *io.n_groups * 64u : bp.n_samples;
     else {
         n_shadow = *io.n_shadow;
         total = n_shadow + *io.n_chain;
@@ -1066,6 +1068,10 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
                 uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 uint32_t idx = w_next + rank;
                 w_next += take;
+                if (RAYGEN && io.groups != nullptr && rank < take) {
+                    idx = io.groups[idx >> 6] * 64u + (idx & 63u);   // camera-ray cull: work item -> sample
+                    if (idx >= bp.n_samples) rank = 0xFFFFFFFFu;     // the batch's last group may be short
+                }
                 if (cur == REF_IDLE && rank < take) {
                     if (RAYGEN) {
                         uint32_t pix = idx / fp.spp, si = idx - pix * fp.spp;
@@ -1267,6 +1273,167 @@ __global__ void __launch_bounds__(TRACE_THREADS) TRR_OCCUPANCY_ATTR k_trace_leve
             atomicAdd(io.counters + KC_WUNI, c_wuni);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Camera-ray cull.  A camera ray that passes no triangle's own box has an empty candidate set in the reference
+// (object.rs:191-195) and is skybox(direction) (mod.rs:119) -- most of a frame, where the scene fills little of it.  Per
+// FRAME: (1) k_cover_boxes projects the scene's cover boxes (made once per scene by k_cover_expand: the child boxes of one
+// level of every object's tree, each the union of the own boxes -- triangle.rs:88-95 -- of the triangles below it)
+// onto the image and marks the 8x8-pixel tiles whose pixels have a sample position inside the projection's bounding
+// rectangle, widened by a pixel on every side on top of the samples' own spread around the pixel corner (mod.rs:233-240: from
+// -1/s to +1 horizontally, to (yi_max + 1)/s vertically); rectangles of many tiles go through k_cover_big.  A ray through an
+// unmarked tile misses every leaf box by at least that pixel, four orders of magnitude beyond the rounding of the slab tests
+// it would have failed.  Boxes wholly behind the camera plane cannot be met by a camera ray (all of which point forward,
+// camera.rs:32); a box AT the plane, or a bound that is not finite, has no bounded projection: the frame then counts as
+// covered everywhere (flags[0]).  Per BATCH: (2) k_cover_groups lists the batch's 64-sample groups that own a pixel of a marked tile; the
+// camera-ray launch takes its work items from that list, the samples of the other groups are recorded as misses (nlev 0)
+// without a ray.  TRR_CAMCULL=0 switches it off; scenes with an object of at most four triangles (whose root is a leaf, and
+// which bvh::traverse returns without a box test when it is one triangle) never use it.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t COVER_SMALL = 16u;   // tiles a thread marks itself
+
+__global__ void __launch_bounds__(256) k_cover_expand(const Node4* nodes, const uint32_t* node_begin, uint32_t n_objs, const uint32_t* frontier_in,
+                                                      uint32_t n_in, uint32_t* frontier_out, uint32_t* n_out, CoverBox* boxes, uint32_t* n_boxes,
+                                                      uint32_t box_cap, uint32_t last) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if ((i >> 2) >= n_in) return;
+    const uint32_t node = frontier_in[i >> 2], k = i & 3u;
+    const Node4* nd = nodes + node;
+    const uint32_t ref = nd->child[k];
+    if (ref == REF_EMPTY) return;
+    if (!last && !(ref & REF_LEAF)) {
+        frontier_out[atomicAdd(n_out, 1u)] = ref;   // at most 4 * n_in entries: the host sizes the buffer for that
+        return;
+    }
+    uint32_t a = 0, b = n_objs;   // the node's object: node_begin[a] <= node < node_begin[b]
+    while (b - a > 1u) {
+        const uint32_t m = (a + b) >> 1;
+        if (node_begin[m] <= node) a = m; else b = m;
+    }
+    const uint32_t slot = atomicAdd(n_boxes, 1u);
+    if (slot >= box_cap) return;   // (the host stops expanding before this can happen and checks the count)
+    CoverBox cb;
+    cb.lo[0] = nd->lox[k]; cb.lo[1] = nd->loy[k]; cb.lo[2] = nd->loz[k];
+    cb.hi[0] = nd->hix[k]; cb.hi[1] = nd->hiy[k]; cb.hi[2] = nd->hiz[k];
+    cb.obj = a; cb.pad = 0;
+    boxes[slot] = cb;
+}
+
+void launch_cover_expand(hipStream_t st, const Node4* nodes, const uint32_t* node_begin, uint32_t n_objs, const uint32_t* frontier_in,
+                         uint32_t n_in, uint32_t* frontier_out, uint32_t* n_out, CoverBox* boxes, uint32_t* n_boxes, uint32_t box_cap, bool last) {
+    if (n_in == 0) return;
+    hipLaunchKernelGGL(k_cover_expand, dim3((n_in * 4u + 255u) / 256u), dim3(256), 0, st, nodes, node_begin, n_objs, frontier_in, n_in,
+                       frontier_out, n_out, boxes, n_boxes, box_cap, last ? 1u : 0u);
+}
+
+__global__ void __launch_bounds__(256) k_cover_boxes(FrameParams fp, CoverIO io) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= io.n_boxes) return;
+    const CoverBox cbx = io.boxes[i];
+    const float lo[3] = {cbx.lo[0], cbx.lo[1], cbx.lo[2]}, hi[3] = {cbx.hi[0], cbx.hi[1], cbx.hi[2]};
+    bool finite = true;
+    for (int a = 0; a < 3; ++a) finite = finite && fabsf(lo[a]) < INFINITY && fabsf(hi[a]) < INFINITY;   // false for NaN too
+    if (!finite) { atomicOr(io.flags, 1u); return; }
+    const float* fwd = fp.objs[cbx.obj].fwd;
+    const F3 cx = f3(fp.cam_x[0], fp.cam_x[1], fp.cam_x[2]), cy = f3(fp.cam_y[0], fp.cam_y[1], fp.cam_y[2]),
+             cz = f3(fp.cam_z[0], fp.cam_z[1], fp.cam_z[2]), cp = f3(fp.cam_pos[0], fp.cam_pos[1], fp.cam_pos[2]);
+    float A[8], B[8], C[8];
+    float zmin = INFINITY, zmax = -INFINITY, size = 0.0f;
+    for (int c = 0; c < 8; ++c) {
+        const F3 v = xform_point(fwd, f3((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2])) - cp;
+        A[c] = dot(v, cx); B[c] = dot(v, cy); C[c] = dot(v, cz);   // camera space: x right, y up, z BACKWARD (in front: C < 0)
+        zmin = fminf(zmin, C[c]); zmax = fmaxf(zmax, C[c]);
+        size = fmaxf(size, fmaxf(fmaxf(fabsf(A[c]), fabsf(B[c])), fabsf(C[c])));
+    }
+    if (!(size < INFINITY)) { atomicOr(io.flags, 1u); return; }
+    const float eps = 1.0e-5f * size + 1.0e-30f;
+    if (zmin > eps) return;                                  // wholly behind the camera plane: no forward ray meets it
+    if (!(zmax < -eps)) { atomicOr(io.flags, 1u); return; }  // at the plane: no bounded projection
+    // ray through (X, Y) (mod.rs:251-252): d_cam = (X, -Y, focal), so a point (A, B, C) lies on the ray X = focal A / C, Y = -focal B / C
+    const float w = (float)fp.width, h = (float)fp.height, aspect = w / h;
+    float px0 = INFINITY, px1 = -INFINITY, py0 = INFINITY, py1 = -INFINITY;
+    for (int c = 0; c < 8; ++c) {
+        const float X = fp.cam_focal * A[c] / C[c], Y = -fp.cam_focal * B[c] / C[c];
+        const float px = (X / aspect + 1.0f) * 0.5f * w, py = (Y + 1.0f) * 0.5f * h;   // continuous pixel coordinates of the sample
+        px0 = fminf(px0, px); px1 = fmaxf(px1, px); py0 = fminf(py0, py); py1 = fmaxf(py1, py);
+    }
+    if (!(px0 <= px1) || !(py0 <= py1)) { atomicOr(io.flags, 1u); return; }   // NaN: cannot happen after the checks above
+    // pixels with a sample position inside the rectangle, the rectangle widened by the pads
+    const float fx0 = floorf(fmaxf(px0 - io.pad_x_lo, -1.0f)), fx1 = ceilf(fminf(px1 + io.pad_x_hi, w));
+    const float fy0 = floorf(fmaxf(py0 - io.pad_y_lo, -1.0f)), fy1 = ceilf(fminf(py1 + io.pad_y_hi, h));
+    if (fx1 < 0.0f || fy1 < 0.0f || fx0 > w - 1.0f || fy0 > h - 1.0f) return;   // off the image
+    const uint32_t x0 = (uint32_t)fmaxf(fx0, 0.0f), x1 = (uint32_t)fminf(fx1, w - 1.0f), y0 = (uint32_t)fmaxf(fy0, 0.0f), y1 = (uint32_t)fminf(fy1, h - 1.0f);
+    const uint32_t tx0 = x0 >> 3, tx1 = x1 >> 3, ty0 = y0 >> 3, ty1 = y1 >> 3;
+    if ((tx1 - tx0 + 1u) * (ty1 - ty0 + 1u) <= COVER_SMALL) {
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) io.mask[(size_t)ty * io.tiles_x + tx] = 1;
+    } else {
+        const uint32_t slot = atomicAdd(io.n_big, 1u);
+        if (slot < io.big_cap) io.big[slot] = make_uint4(tx0, ty0, tx1, ty1);
+        else atomicOr(io.flags, 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cover_big(CoverIO io) {
+    const uint32_t n = min(*io.n_big, io.big_cap);
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const uint4 r = io.big[e];
+        const uint32_t bw = r.z - r.x + 1u, cnt = bw * (r.w - r.y + 1u);
+        for (uint32_t t = threadIdx.x; t < cnt; t += 256u) io.mask[(size_t)(r.y + t / bw) * io.tiles_x + r.x + t % bw] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cover_groups(FrameParams fp, BatchParams bp, CoverIO io) {
+    __shared__ uint32_t s_cnt[4], s_base;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n_groups = (bp.n_samples + 63u) / 64u;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    bool active = false;
+    uint32_t skipped = 0;
+    if (g < n_groups) {
+        const uint32_t s0 = g * 64u, s1 = min(s0 + 63u, bp.n_samples - 1u);
+        active = *io.flags != 0u;
+        const uint32_t p0 = s0 / fp.spp, p1 = s1 / fp.spp;
+        for (uint32_t p = p0; p <= p1 && !active; ++p) {
+            const PixelPos pp = pixel_of(fp, bp, p);
+            active = io.mask[(size_t)(pp.y >> 3) * io.tiles_x + (pp.x >> 3)] != 0;
+        }
+        if (!active) {
+            // its samples are camera rays that meet nothing: nlev 0 (the buffer's size is a multiple of 64)
+            uint4* z = reinterpret_cast<uint4*>(io.nlev + (size_t)s0);
+            z[0] = z[1] = z[2] = z[3] = make_uint4(0, 0, 0, 0);
+            skipped = s1 - s0 + 1u;
+        }
+    }
+    // the list keeps the groups' order inside a block; one atomic per block
+    const unsigned long long am = __ballot(active);
+    if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(am);
+    for (int off = 32; off > 0; off >>= 1) skipped += __shfl_down(skipped, off);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = t ? atomicAdd(io.n_groups, t) : 0u;
+    }
+    __syncthreads();
+    if (active) {
+        uint32_t base = s_base;
+        for (uint32_t k = 0; k < wv; ++k) base += s_cnt[k];
+        io.groups[base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = g;
+    }
+    if (lane == 0 && skipped != 0u) atomicAdd(io.counters + KC_PRIMARY_CULLED, (unsigned long long)skipped);
+}
+
+// once per frame: the tile mask (its memory cleared by the caller)
+void launch_cover_mask(hipStream_t st, const FrameParams& fp, const CoverIO& io) {
+    if (io.n_boxes == 0u) return;
+    hipLaunchKernelGGL(k_cover_boxes, dim3((io.n_boxes + 255u) / 256u), dim3(256), 0, st, fp, io);
+    hipLaunchKernelGGL(k_cover_big, dim3(256), dim3(256), 0, st, io);
+}
+// once per batch: the list of its groups that are traced
+void launch_cover_groups(hipStream_t st, const FrameParams& fp, const BatchParams& bp, const CoverIO& io) {
+    const uint32_t n_groups = (bp.n_samples + 63u) / 64u;
+    hipLaunchKernelGGL(k_cover_groups, dim3((n_groups + 255u) / 256u), dim3(256), 0, st, fp, bp, io);
 }
 
 // k_setup: one chain ray's closest hit -> shaded-hit record + secondary rays (mod.rs:116-153, 199-206; object.rs:198-219)

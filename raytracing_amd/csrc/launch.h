@@ -32,6 +32,8 @@ struct TraceIO {
     uint32_t* first_tri;
     unsigned long long* counters; // kernel counters (device_types.h: KC_*)
     uint2* spill;                 // traversal-stack spill, per thread of the grid
+    const uint32_t* groups;       // nullable (camera-ray cull): the 64-sample groups that are traced; work item i is sample
+    const uint32_t* n_groups;     //   groups[i / 64] * 64 + i % 64, and there are *n_groups * 64 work items
 };
 // the level-synchronous schedule's kernels
 struct LevelIO {
@@ -49,6 +51,33 @@ struct LevelIO {
     uint32_t* first_tri;
     unsigned long long* counters;
     uint2* spill;
+    const uint32_t* groups;       // RAYGEN, nullable (camera-ray cull): see TraceIO
+    const uint32_t* n_groups;
+};
+// Camera-ray cull (kernels.hip: k_cover_*): which 8x8-pixel tiles of the frame can see a box of the scene at all.
+// A scene's "cover boxes" are made once, when it is created: the child boxes of all nodes of one tree level (plus the leaves
+// above it), at most COVER_BOX_BUDGET of them -- every triangle's own box lies inside one of them.
+struct alignas(16) CoverBox {
+    float lo[3];
+    uint32_t obj;
+    float hi[3];
+    uint32_t pad;
+};
+constexpr uint32_t COVER_BOX_BUDGET = 1u << 16;
+struct CoverIO {
+    uint8_t* mask;                // [tiles_y][tiles_x] 1 = some leaf box projects onto the tile (or too near to tell)
+    uint32_t tiles_x, tiles_y;
+    uint32_t* flags;              // [0] != 0: no statement possible this frame (a box at the camera plane, a bound not finite): all tiles count
+    const CoverBox* boxes;        // the scene's cover boxes (object space)
+    uint32_t n_boxes;
+    float pad_x_lo, pad_x_hi, pad_y_lo, pad_y_hi;   // pixels a box's projection is widened by: the samples of a pixel lie around its corner
+    uint4* big;                   // rectangles of more than COVER_SMALL tiles, filled by k_cover_big
+    uint32_t* n_big;
+    uint32_t big_cap;
+    uint32_t* groups;             // out: the batch's 64-sample groups with a covered pixel, n_groups of them
+    uint32_t* n_groups;
+    uint8_t* nlev;                // groups left out: their samples are camera rays that miss (nlev 0)
+    unsigned long long* counters;
 };
 struct SetupIO {
     const float4* chain_in;
@@ -82,6 +111,12 @@ void launch_trace(bool count, uint32_t grid, hipStream_t st, const FrameParams& 
 int level_blocks_per_cu(bool raygen, bool count);
 void launch_trace_level(bool raygen, bool count, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
                         const LevelIO& io);
+void launch_cover_mask(hipStream_t st, const FrameParams& fp, const CoverIO& io);
+void launch_cover_groups(hipStream_t st, const FrameParams& fp, const BatchParams& bp, const CoverIO& io);
+// One round of the top-down expansion that makes a scene's cover boxes: the children of the nodes in frontier_in go to
+// frontier_out (inner nodes) or to boxes (leaves; with `last`, every child).  node_begin: first node of every object.
+void launch_cover_expand(hipStream_t st, const Node4* nodes, const uint32_t* node_begin, uint32_t n_objs, const uint32_t* frontier_in,
+                         uint32_t n_in, uint32_t* frontier_out, uint32_t* n_out, CoverBox* boxes, uint32_t* n_boxes, uint32_t box_cap, bool last);
 void launch_setup(bool level0, uint32_t grid, hipStream_t st, const FrameParams& fp, const BatchParams& bp, const SetupIO& io,
                   uint32_t lvl);
 void launch_resolve(uint32_t grid_samples, uint32_t grid_pixels, hipStream_t st, const FrameParams& fp, const BatchParams& bp,
