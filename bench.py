@@ -15,7 +15,11 @@ untimed-for-the-metric loop with two frames in flight gives the throughput of a 
 
 Rays are counted by the rule of SURVEY.md section 8(d) (primaries + one shadow query per shaded hit and light + one
 reflection per reflective hit + transparency-march queries); the CPU baseline is credited the same rays for the
-same blocks, so GPU/CPU ratio == time ratio.
+same blocks, so GPU/CPU ratio == time ratio.  `value` is that count over the frame time -- the rays of the reference
+algorithm that the frame ANSWERS per second.  Two kinds of them are answered without a traversal of their own and are listed
+in `config`: shadow rays whose light adds exactly nothing at the hit (round 2) and camera rays through image tiles that no
+box of the scene projects onto (round 3); `config.mrays_traced_per_s` is the rate of the rays that were traced one by one,
+which is what `value` meant in round 2 (BENCH_r02: 7503).
 
 Roofline: the path is fp32 VALU work on cache-resident data -- no MFMA, 3 % of the HBM peak -- so
 the roof is the fp32 vector peak.  `achieved` = ALGORITHMIC flops of a frame / frame time, the flops from the counter
@@ -56,7 +60,7 @@ N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2   # 256 CUs x 4 SIMDs; a wave64 V
 def frame_flops(st, n_lights, n_objs=1) -> float:
     leaf_boxes = max(0, st.box_tests - 4 * st.node_visits)
     shaded = st.rays_shadow / max(1, n_lights)
-    traced = st.rays() - st.rays_shadow_culled   # a culled shadow ray is never started
+    traced = st.rays() - st.rays_shadow_culled - st.rays_primary_culled   # a culled ray is never started
     return (NODE_FLOP * st.node_visits + BOX_FLOP * leaf_boxes + TRI_FLOP * st.tri_tests + RAY_FLOP * traced * n_objs +
             shaded * (SETUP_FLOP + HIT_FLOP + LIGHT_FLOP * n_lights))
 
@@ -149,14 +153,14 @@ def main():
         stats = [N.Stats()]
         sr.render(stats=stats[-1])
         torch.cuda.synchronize()
-    my_rays, my_culled = stats[-1].rays(), stats[-1].rays_shadow_culled
+    my_rays, my_culled, my_pculled = stats[-1].rays(), stats[-1].rays_shadow_culled, stats[-1].rays_primary_culled
     if distributed:
-        t = torch.tensor([my_rays, my_culled], dtype=torch.int64, device="cuda")
+        t = torch.tensor([my_rays, my_culled, my_pculled], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        frame_rays, frame_culled = int(t[0].item()), int(t[1].item())
+        frame_rays, frame_culled, frame_pculled = int(t[0].item()), int(t[1].item()), int(t[2].item())
     else:
-        frame_rays, frame_culled = int(my_rays), int(my_culled)
-    traced_rays = frame_rays - frame_culled   # what `value` counts: rays that were actually traced
+        frame_rays, frame_culled, frame_pculled = int(my_rays), int(my_culled), int(my_pculled)
+    traced_rays = frame_rays - frame_culled - frame_pculled   # rays with a traversal of their own
 
     # ---- untimed for the metric: the same K frames with two in flight (throughput of a frame sequence) -------------
     pipelined = None
@@ -166,7 +170,8 @@ def main():
             sr2.render()
         el2 = timed_loop(sr2, args.steps, None)
         pipelined = {"frames_in_flight": 2, "ms_per_frame": round(el2 / args.steps * 1e3, 3),
-                     "mrays_per_s": round(traced_rays * args.steps / el2 / 1e6, 2)}
+                     "mrays_per_s": round(frame_rays * args.steps / el2 / 1e6, 2),
+                     "mrays_traced_per_s": round(traced_rays * args.steps / el2 / 1e6, 2)}
         del sr2
 
     # ---- untimed: counter build of rank 0's shard -> nodes visited / triangles tested (algorithmic flops) ----------
@@ -252,7 +257,7 @@ def main():
 
     if rank == 0:
         ms = elapsed / max(1, args.steps) * 1e3
-        value = traced_rays * args.steps / elapsed / 1e6 if elapsed > 0 else 0.0
+        value = frame_rays * args.steps / elapsed / 1e6 if elapsed > 0 else 0.0
         out = {
             "metric": "Mrays/sec (whole node) at 4K car_objs scene", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -260,12 +265,14 @@ def main():
             "config": {"workload": f"car_objs stand-in (procedural, {scene.triangle_count()} triangles, one object) "
                                    f"{args.width}x{args.height}, {args.spp} spp, max_depth {args.max_depth} "
                                    f"(reflection depth {args.max_depth - 1}), {n_lights} lights, tiles sharded over {world} GPU(s)",
-                       "rays_per_frame": traced_rays, "algorithm_rays_per_frame": frame_rays,
-                       "shadow_rays_culled_per_frame": frame_culled,
-                       "rays_note": "value counts the rays that were traced; the reference algorithm casts algorithm_rays_per_frame "
-                                    "(SURVEY.md 8d), shadow_rays_culled_per_frame of which are answered without a traversal because "
-                                    "their light adds exactly nothing at the hit (DESIGN.md 4, same image bit for bit)",
-                       "mrays_algorithm_per_s": round(frame_rays * args.steps / elapsed / 1e6, 2) if elapsed > 0 else 0.0,
+                       "rays_per_frame": frame_rays, "rays_traced_per_frame": traced_rays,
+                       "shadow_rays_culled_per_frame": frame_culled, "camera_rays_culled_per_frame": frame_pculled,
+                       "rays_note": "value counts the rays of the reference algorithm (SURVEY.md 8d: the count the CPU baseline is credited too) "
+                                    "that a frame answers; shadow_rays_culled_per_frame of them need no answer (their light adds exactly nothing "
+                                    "at the hit) and camera_rays_culled_per_frame are answered 'no hit' for a whole 8x8-pixel tile at once (no box "
+                                    "of the scene projects onto it) -- same image bit for bit, DESIGN.md 4.  mrays_traced_per_s counts only the "
+                                    "rays traced one by one: round 2's meaning of value",
+                       "mrays_traced_per_s": round(traced_rays * args.steps / elapsed / 1e6, 2) if elapsed > 0 else 0.0,
                        "scene_upload_s": round(upload_s, 2), "bvh_build": args.build,
                        "frames_in_flight": args.frames_in_flight,
                        # HIP hardware queues the library planned its streams for (this script asks for 16 before HIP starts; the

@@ -31,7 +31,7 @@ rt.render_shard_device(0, 1, strip.data_ptr(), sb, stats=st, counters=True)
 torch.cuda.synchronize()
 rays = st.rays()
 g = 64.0 / max(1, rays)
-print(f"cfg{c}: rays {rays} (primary {st.rays_primary} shadow {st.rays_shadow} refl {st.rays_reflection} march {st.rays_march}; shadow rays culled {st.rays_shadow_culled} = {st.rays_shadow_culled / max(1, st.rays_shadow):.3f})")
+print(f"cfg{c}: rays {rays} (primary {st.rays_primary} shadow {st.rays_shadow} refl {st.rays_reflection} march {st.rays_march}; shadow rays culled {st.rays_shadow_culled} = {st.rays_shadow_culled / max(1, st.rays_shadow):.3f}; camera rays culled {st.rays_primary_culled} = {st.rays_primary_culled / max(1, st.rays_primary):.3f})")
 print(f"  per ray: nodes {st.node_visits / rays:.2f} tris {st.tri_tests / rays:.2f} boxes {st.box_tests / rays:.2f}")
 print(f"  per 64 rays: wave node steps {st.wave_node_steps * g:.2f} tri steps {st.wave_tri_steps * g:.2f} outer {st.wave_outer_steps * g:.2f} "
       f"trans {st.wave_trans_steps * g:.2f} (lanes per trans {st.trans_lanes / max(1, st.wave_trans_steps):.1f})")
