@@ -24,6 +24,8 @@ ENVS = [
     {"TRR_SCHEDULE": "levels", "TRR_RESOLVE": "two_pass"}, {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1"},
     {"TRR_SCHEDULE": "levels", "TRR_CULL": "0"}, {"TRR_SCHEDULE": "persistent", "TRR_CULL": "0"},
     {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "0", "TRR_DRAIN_LEVEL": "1"}, {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1", "TRR_SHADOW": "wide"},
+    {"TRR_CAMCULL": "0"}, {"TRR_SCHEDULE": "persistent", "TRR_CAMCULL": "0"}, {"TRR_SCHEDULE": "levels", "TRR_STAGE": "1"},
+    {"TRR_SCHEDULE": "levels", "TRR_STAGE": "1", "TRR_SPLIT": "1"},
 ]
 KEYS = sorted({k for e in ENVS for k in e})
 ctx = Context(0)

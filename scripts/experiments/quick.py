@@ -4,7 +4,8 @@ import os as _os
 
 # More hardware queues than HIP's default of 4 (which the GPU box also exports): the library runs up to nine streams per
 # frame.  Must be in the environment before the HIP runtime starts, i.e. before torch touches the GPU.
-if int(_os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 16:
+# TRR_KEEP_HW_QUEUES=1 leaves the environment's own value (the GPU box exports 4) in place, for the 4-queue figures.
+if not _os.environ.get("TRR_KEEP_HW_QUEUES") and int(_os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 16:
     _os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
 import hashlib
@@ -32,6 +33,7 @@ cfgs = {
     "s2": (lambda: standin.standin_car(3840, 2160, anti_aliasing=True, samples=16), 5, 2),
 }
 out = []
+print(f"hardware queues the library plans for: {N.lib().trr_hw_queues()}", flush=True)
 for c in which:
     make, md, n = cfgs[c]
     rt = Raytracer(make(), max_depth=md)
