@@ -96,7 +96,7 @@ def main():
         torch.cuda.synchronize()
         recs[c] = {"config": c, "workload": name, "triangles": sc.triangle_count(), "resolution": [w, h], "max_depth": md,
                    "gpu_ms_per_frame": round(best * 1e3, 3), "rays_per_frame": int(st.rays()),
-                   "shadow_rays_culled_per_frame": int(st.rays_shadow_culled),
+                   "shadow_rays_culled_per_frame": int(st.rays_shadow_culled), "camera_rays_culled_per_frame": int(st.rays_primary_culled),
                    "gpu_mrays_per_s": round(st.rays() / best / 1e6, 1), "scene_upload_s": round(upload_s, 2),
                    "nodes_per_ray": round(cst.node_visits / max(1, cst.rays()), 2),
                    "tris_per_ray": round(cst.tri_tests / max(1, cst.rays()), 2),
