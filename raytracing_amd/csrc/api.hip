@@ -1199,6 +1199,9 @@ struct BatchGrids {
     uint32_t levels;              // levels: chain levels that can hold a hit (1 when no material is a mirror, else max_depth)
     uint32_t cull;                // levels: 1 = k_setup culls the shadow rays of lights that add exactly nothing (kernels.hip)
     uint32_t split;               // levels: 1 = reflection rays and shadow rays in launches of their own, on streams of their own
+    uint32_t split_drain;         // levels, split: 1 = after level 0's set-up ONE k_trace launch follows every reflection chain to its
+                                  // end (levels >= 1: their hits, shadow rays and further reflections) while level 0's shadow rays
+                                  // are traced on their own stream -- the batch's dependent chain is then four launches long
     uint32_t drain_level;         // levels: from this level's set-up on, ONE k_trace launch (grid `trace`) drains the rest of the
                                   // batch -- the level's shadow rays, the next level's reflection rays and all they spawn
                                   // (NO_DRAIN: never)
@@ -1322,6 +1325,24 @@ static void queue_batch(const FrameParams& fp, const BatchParams& bp, const Work
                 ev_end(sa);
                 (void)hipEventRecord(w.sync_ev[2 * lvl + 1], sa);
                 last_aux[lvl == 0 ? 0 : 1] = w.sync_ev[2 * lvl + 1];
+                if (g.split_drain != 0u && lvl == 0 && n_levels >= 2 && w.wqueue != nullptr) {
+                    // everything deeper than level 0 in one persistent launch: level 1's reflection rays are its work items
+                    TraceIO d{};
+                    d.hits = w.hits; d.level = w.level; d.term = w.term; d.nlev = w.nlev; d.occ = w.occ;
+                    d.wqueue = w.wqueue;
+                    d.qcap = queue_capacity(fp.n_lights);
+                    d.counters = kc;
+                    d.spill = w.spill;
+                    d.cull = g.cull;
+                    d.work_counter = cw + CW_WORK + CW_WORK_STRIDE * 1;
+                    d.src_q = w.chain_q[1]; d.src_n = cw + CW_NCHAIN + 1; d.src_cap = bp.cap;
+                    d.src_compact = 0; d.src_level = 0;
+                    d.chunk_min = std::max(1u, g.chunk_min[1]);
+                    ev_begin(0, s_);
+                    launch_trace(count, g.trace, s_, fp, bp, d);
+                    ev_end(s_);
+                    break;
+                }
                 // the next level's reflection rays, on the chain
                 if (lvl + 1 < n_levels) {
                     LevelIO tc = tio;
@@ -1571,11 +1592,14 @@ static int render_shard_impl(trr_ctx* ctx, trr_scene* sc, float delta, uint32_t 
         grids.split = (g_hw_queues >= 8 && total_samples <= (1ull << 26) && grids.levels >= 2) ? 1u : 0u;
     }
     if (const char* e = std::getenv("TRR_SPLIT")) grids.split = std::atoi(e) != 0 ? 1u : 0u;
+    grids.split_drain = 0;
+    if (const char* e = std::getenv("TRR_SPLIT_DRAIN")) grids.split_drain = std::atoi(e) != 0 ? 1u : 0u;
     // a pipelined caller's small frames hide their thin deep levels behind the other frame; a big frame (four batches on three
     // lanes, e.g. 4K x 16 spp: 29.4 ms without a drain, 28.2 / 27.8 with one from level 2 / 3) gains from it like a lone one
     grids.drain_level = (flags & TRR_FLAG_PIPELINED) ? (total_samples > (1ull << 26) ? 3u : NO_DRAIN) : 2u;
     if (const char* e = std::getenv("TRR_DRAIN_LEVEL")) grids.drain_level = std::atoi(e) < 0 ? NO_DRAIN : (uint32_t)std::atoi(e);
-    const bool drains = schedule == SCHED_LEVELS && grids.split == 0 && grids.drain_level != NO_DRAIN && grids.drain_level + 1 < max_depth;
+    const bool drains = schedule == SCHED_LEVELS && ((grids.split == 0 && grids.drain_level != NO_DRAIN && grids.drain_level + 1 < max_depth) ||
+                                                     (grids.split != 0 && grids.split_drain != 0 && max_depth >= 2));
     const uint32_t trace_grid = schedule == SCHED_PERSISTENT ? grids.trace
                                                              : std::max(std::max(grids.raygen, grids.secondary), drains ? grids.trace : 0u);   // sizes the stack-spill area
     if (std::getenv("TRR_DEBUG"))

@@ -21,7 +21,7 @@ def ctx():
 
 
 def _render(ctx, sc, max_depth, env):
-    keys = ("TRR_SCHEDULE", "TRR_DRAIN_LEVEL", "TRR_SHADOW", "TRR_RESOLVE", "TRR_BATCHES", "TRR_SPLIT", "TRR_STAGE")
+    keys = ("TRR_SCHEDULE", "TRR_DRAIN_LEVEL", "TRR_SHADOW", "TRR_RESOLVE", "TRR_BATCHES", "TRR_SPLIT", "TRR_STAGE", "TRR_SPLIT_DRAIN")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)
@@ -54,6 +54,8 @@ VARIANTS = {
     "levels, wide shadow records, drain from level 0": {"TRR_SCHEDULE": "levels", "TRR_SHADOW": "wide", "TRR_DRAIN_LEVEL": "0", "TRR_SPLIT": "0"},
     "levels, two resolve passes": {"TRR_SCHEDULE": "levels", "TRR_RESOLVE": "two_pass"},
     "levels, five batches": {"TRR_SCHEDULE": "levels", "TRR_BATCHES": "5"},
+    "levels, split, deep levels drained by one launch": {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1", "TRR_SPLIT_DRAIN": "1"},
+    "levels, split, drained, wide shadow records, three batches": {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1", "TRR_SPLIT_DRAIN": "1", "TRR_SHADOW": "wide", "TRR_BATCHES": "3"},
     "levels, staged ray starts": {"TRR_SCHEDULE": "levels", "TRR_STAGE": "1", "TRR_SPLIT": "0", "TRR_DRAIN_LEVEL": "-1"},
     "levels, staged ray starts, split, wide shadow records": {"TRR_SCHEDULE": "levels", "TRR_STAGE": "1", "TRR_SPLIT": "1", "TRR_SHADOW": "wide"},
 }
