@@ -19,7 +19,19 @@
                     if (lane == first_lane) c_wnode++;
                     // node steps in which every participating lane stands on the SAME node
                     const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-#ifndef TRR_COUNT_WAIT
+#if defined(TRR_COUNT_DISTINCT)
+                    {   // experiment: distinct nodes among the lanes of this node step (what a shared-front traversal would visit one by one)
+                        unsigned long long left = am;
+                        uint32_t distinct = 0;
+                        while (left != 0ull) {
+                            const uint32_t l0 = (uint32_t)__ffsll((long long)left) - 1u;
+                            const uint32_t c0 = (uint32_t)__shfl((int)cur, (int)l0);
+                            left &= ~__ballot(cur == c0);
+                            ++distinct;
+                        }
+                        if (lane == first_lane) c_wuni += distinct;
+                    }
+#elif !defined(TRR_COUNT_WAIT)
                     if (__ballot(cur == cur0) == am && lane == first_lane) c_wuni++;
 #endif
                 }

@@ -42,5 +42,7 @@ leaf_boxes = st.box_tests - 4 * st.node_visits
 print(f"  leaf steps: own-box tests per wave step {leaf_boxes / max(1, st.wave_tri_steps):.1f} of 128 lane-slots = {leaf_boxes / max(1, 128 * st.wave_tri_steps):.3f}")
 if os.environ.get("TRR_COUNT_WAIT"):   # a -DTRR_COUNT_WAIT build counts waiting lanes in the uniform-node-step counter
     print(f"  lanes waiting with a finished traversal per outer step {st.wave_uniform_node_steps / max(1, 64 * st.wave_outer_steps):.3f}")
+if os.environ.get("TRR_COUNT_DISTINCT"):   # a -DTRR_COUNT_DISTINCT build sums the distinct nodes per node step in that counter
+    print(f"  distinct nodes per wave node step {st.wave_uniform_node_steps / max(1, st.wave_node_steps):.2f} (lanes per step {st.node_visits / max(1, st.wave_node_steps):.1f})")
 print(f"  ms_total {st.ms_total:.2f} trace {st.ms_trace:.2f} shade {st.ms_shade:.2f} launches {st.trace_launches} overflows {st.queue_overflows}")
 rt.close()
