@@ -8,8 +8,9 @@
 //
 // Pipeline (all HBM-bound, one pass each over n triangles): prep (raw 96-B triangles -> box, InterpRec, live flag,
 // centroid bounds) -> 63-bit Morton keys -> hipCUB radix sort of (key, triangle) -> gather of the 64-B TriRecs and the
-// boxes into leaf order -> Karras radix tree -> box fit by range unions over a pairwise-union pyramid (no atomics, no
-// fences: lbvh_core.h) -> level-by-level collapse into 128-B 4-wide nodes.
+// boxes into leaf order -> Karras radix tree -> its small subtrees ("treelets") rebuilt with surface-area splits
+// (lbvh_core.h) -> box fit by range unions over a pairwise-union pyramid (no atomics, no fences) -> level-by-level
+// collapse into 128-B 4-wide nodes.
 #include "build_device.h"
 
 #include <hipcub/hipcub.hpp>
@@ -52,6 +53,8 @@ struct Globals {            // one small device record per build, zero-initialis
     uint32_t n_big;         // inner nodes of the binary tree over more than MAX_LEAF triangles (bound on the 4-wide nodes)
     uint32_t n_nodes;       // 4-wide nodes allocated so far
     uint32_t stack_need;    // traversal stack entries the tree can need (device_types.h, TRACE_STACK_ENTRIES)
+    uint32_t n_roots;       // small treelet roots (k_hier, k_treelet_top): one thread rebuilds each
+    uint32_t n_roots_big;   // big treelet roots (k_hier): one wavefront splits each down to small ones
 };
 
 __device__ inline void load_raw(const float* raw, uint32_t t, float f[24]) {
@@ -170,20 +173,233 @@ __global__ void __launch_bounds__(BT) k_keys(const Box3* __restrict__ boxes, con
     vals[t] = t;
 }
 
-__global__ void __launch_bounds__(BT) k_hier(const uint64_t* __restrict__ keys, uint32_t n, lbvh::Tree tree, Globals* g) {
+// The radix tree; with treelet_max >= 3 every inner node also reports the children that root a treelet (a subtree of at most
+// treelet_max triangles below a bigger node; lbvh_core.h) -- the parent knows its children's ranges from its own split.
+// Treelets of more than small_max triangles go to the `big` list (k_treelet_top), the others to `roots` (k_treelet).
+__global__ void __launch_bounds__(BT) k_hier(const uint64_t* __restrict__ keys, uint32_t n, lbvh::Tree tree, uint32_t treelet_max, uint32_t small_max,
+                                             uint32_t* __restrict__ roots, uint32_t* __restrict__ big, Globals* g) {
+    const uint32_t i = blockIdx.x * BT + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t mine[2];
+    uint32_t n_mine = 0;
+    if (i + 1 < n) {
+        lbvh::build_inner(keys, (int64_t)n, (int64_t)i, tree);
+        if (treelet_max >= 3u) {
+            const uint32_t f = tree.first[i], l = tree.last[i], cl = tree.child_l[i], cr = tree.child_r[i];
+            if (l - f + 1u > treelet_max) {
+                if (!(cl & lbvh::LEAF_BIT)) { const uint32_t c = cl - f + 1u; if (c >= 3u && c <= treelet_max) mine[n_mine++] = cl | (c > small_max ? 0x80000000u : 0u); }
+                if (!(cr & lbvh::LEAF_BIT)) { const uint32_t c = l - cr + 1u; if (c >= 3u && c <= treelet_max) mine[n_mine++] = cr | (c > small_max ? 0x80000000u : 0u); }
+            } else if (i == 0u && l - f + 1u >= 3u) {
+                mine[n_mine++] = (l - f + 1u > small_max) ? 0x80000000u : 0u;   // the whole object is one treelet
+            }
+        }
+    }
+    // one same-address atomic per wavefront and list
+    for (uint32_t which = 0; which < 2u; ++which) {
+        uint32_t cnt = 0;
+        for (uint32_t k = 0; k < n_mine; ++k) cnt += ((mine[k] >> 31) == which) ? 1u : 0u;
+        uint32_t incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if (lane >= (uint32_t)o) incl += v;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        uint32_t base = 0;
+        if (lane == 63u && total) base = atomicAdd(which ? &g->n_roots_big : &g->n_roots, total);
+        base = __shfl(base, 63, 64);
+        uint32_t at = base + incl - cnt;
+        for (uint32_t k = 0; k < n_mine; ++k)
+            if ((mine[k] >> 31) == which) (which ? big : roots)[at++] = mine[k] & 0x7FFFFFFFu;
+    }
+}
+
+// One wavefront per BIG treelet: the same binned-SAH splits as lbvh::treelet_rebuild, made by 64 lanes together (bins in LDS,
+// partition through a second buffer), down to ranges of at most small_max triangles, which are appended to `roots` for
+// k_treelet.  The smaller child is always processed first, so the LDS stack holds at most log2(range) pending ranges.
+__global__ void __launch_bounds__(64) k_treelet_top(lbvh::Tree tree, const uint32_t* __restrict__ big, uint32_t n_big_roots, uint32_t small_max,
+                                                    uint32_t* __restrict__ vals, Box3* __restrict__ sbox, uint32_t* __restrict__ vals_tmp,
+                                                    Box3* __restrict__ sbox_tmp, uint32_t* __restrict__ roots, uint32_t roots_cap, Globals* g) {
+    constexpr int NB = lbvh::TL_BINS;
+    __shared__ uint32_t s_lo[3][NB][3], s_hi[3][NB][3], s_cnt[3][NB];
+    constexpr uint32_t STACK = 40;
+    __shared__ uint32_t s_stack[STACK][3];   // node, first, last
+    __shared__ uint32_t s_small[64];
+    __shared__ uint32_t s_nsmall, s_base;
+    if (blockIdx.x >= n_big_roots) return;
+    const uint32_t lane = threadIdx.x;
+    const float inf = __builtin_inff();
+    uint32_t sp = 0;
+    if (lane == 0) {
+        const uint32_t r = big[blockIdx.x];
+        s_stack[0][0] = r; s_stack[0][1] = tree.first[r]; s_stack[0][2] = tree.last[r];
+        s_nsmall = 0;
+    }
+    sp = 1;
+    __syncthreads();
+    auto flush_small = [&]() {   // (called by all lanes)
+        __syncthreads();
+        const uint32_t m = s_nsmall;
+        if (m) {
+            if (lane == 0) s_base = atomicAdd(&g->n_roots, m);
+            __syncthreads();
+            if (lane < m && s_base + lane < roots_cap) roots[s_base + lane] = s_small[lane];
+            __syncthreads();
+            if (lane == 0) s_nsmall = 0;
+            __syncthreads();
+        }
+    };
+    while (sp > 0) {
+        --sp;
+        const uint32_t node = s_stack[sp][0], f = s_stack[sp][1], l = s_stack[sp][2], cnt = l - f + 1u;
+        if (cnt <= small_max || sp + 2u > STACK) {   // (the stack cannot run out: see above; if it did, k_treelet takes the range)
+            if (lane == 0) s_small[s_nsmall++] = node;
+            __syncthreads();
+            if (s_nsmall >= 63u) flush_small();
+            continue;
+        }
+        // centroid bounds of the range
+        float cmin[3] = {inf, inf, inf}, cmax[3] = {-inf, -inf, -inf};
+        for (uint32_t i = f + lane; i <= l; i += 64u) {
+            const Box3 b = sbox[i];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float c = lbvh::centroid_of(b, k);
+                cmin[k] = fminf(cmin[k], c);
+                cmax[k] = fmaxf(cmax[k], c);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { cmin[k] = wave_min(cmin[k]); cmax[k] = wave_max(cmax[k]); }
+        float scale[3];
+        bool axis_ok[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float ext = cmax[k] - cmin[k];
+            axis_ok[k] = (ext > 0.0f) && (ext - ext == 0.0f);
+            scale[k] = axis_ok[k] ? (float)NB / ext : 0.0f;
+        }
+        for (uint32_t w = lane; w < 3u * NB * 3u; w += 64u) { (&s_lo[0][0][0])[w] = 0xFFFFFFFFu; (&s_hi[0][0][0])[w] = 0u; }
+        if (lane < 3u * NB) (&s_cnt[0][0])[lane] = 0u;
+        __syncthreads();
+        for (uint32_t i = f + lane; i <= l; i += 64u) {
+            const Box3 bx = sbox[i];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (!axis_ok[ax]) continue;
+                int b = (int)((lbvh::centroid_of(bx, ax) - cmin[ax]) * scale[ax]);
+                b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                atomicAdd(&s_cnt[ax][b], 1u);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (bx.lo[k] == bx.lo[k]) atomicMin(&s_lo[ax][b][k], f2ord(bx.lo[k]));   // (NaN bounds are left out, as fmin / fmax do)
+                    if (bx.hi[k] == bx.hi[k]) atomicMax(&s_hi[ax][b][k], f2ord(bx.hi[k]));
+                }
+            }
+        }
+        __syncthreads();
+        // lane c < 21 prices the split of axis c / 7 after bin c % 7
+        float cost = inf;
+        if (lane < 3u * (NB - 1)) {
+            const int ax = (int)lane / (NB - 1), plane = (int)lane % (NB - 1);
+            if (axis_ok[ax]) {
+                Box3 L{{inf, inf, inf}, {-inf, -inf, -inf}}, R{{inf, inf, inf}, {-inf, -inf, -inf}};
+                uint32_t nl = 0, nr = 0;
+                for (int b = 0; b < NB; ++b) {
+                    const uint32_t c = s_cnt[ax][b];
+                    if (!c) continue;
+                    Box3 bb;
+                    for (int k = 0; k < 3; ++k) { bb.lo[k] = ord2f(s_lo[ax][b][k]); bb.hi[k] = ord2f(s_hi[ax][b][k]); }
+                    if (b <= plane) { L = lbvh::box_union(L, bb); nl += c; } else { R = lbvh::box_union(R, bb); nr += c; }
+                }
+                if (nl && nr) cost = lbvh::box_half_area(L) * (float)nl + lbvh::box_half_area(R) * (float)nr;
+            }
+        }
+        const float best_cost = wave_min(cost);
+        const unsigned long long winners = __ballot(cost == best_cost && cost < inf);
+        uint32_t mid = f + (cnt - 1u) / 2u;   // no split found (all centroids equal): by count, in the order as it is
+        if (winners) {
+            const int c = __ffsll((long long)winners) - 1;
+            const int ax = c / (NB - 1), best_bin = c % (NB - 1);
+            const float c0 = cmin[ax], sc = scale[ax];
+            // stable partition through the second buffer: left part from f upwards, right part from l downwards
+            uint32_t n_left = 0, n_right = 0;
+            for (uint32_t i0 = f; i0 <= l; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                const bool in = i <= l;
+                Box3 bx{};
+                uint32_t v = 0;
+                bool left = false;
+                if (in) {
+                    bx = sbox[i];
+                    v = vals[i];
+                    int b = (int)((lbvh::centroid_of(bx, ax) - c0) * sc);
+                    b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                    left = b <= best_bin;
+                }
+                const unsigned long long ml = __ballot(in && left), mr = __ballot(in && !left);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (in) {
+                    const uint32_t at = left ? f + n_left + (uint32_t)__popcll(ml & below) : l - n_right - (uint32_t)__popcll(mr & below);
+                    sbox_tmp[at] = bx;
+                    vals_tmp[at] = v;
+                }
+                n_left += (uint32_t)__popcll(ml);
+                n_right += (uint32_t)__popcll(mr);
+            }
+            __syncthreads();
+            for (uint32_t i = f + lane; i <= l; i += 64u) { sbox[i] = sbox_tmp[i]; vals[i] = vals_tmp[i]; }
+            __syncthreads();
+            if (n_left > 0 && n_right > 0) mid = f + n_left - 1u;
+        }
+        const uint32_t lc = (mid == f) ? (lbvh::LEAF_BIT | f) : mid;
+        const uint32_t rc = (mid + 1u == l) ? (lbvh::LEAF_BIT | l) : mid + 1u;
+        if (lane == 0) {
+            tree.child_l[node] = lc;
+            tree.child_r[node] = rc;
+            if (!(lc & lbvh::LEAF_BIT)) { tree.first[lc] = f; tree.last[lc] = mid; }
+            if (!(rc & lbvh::LEAF_BIT)) { tree.first[rc] = mid + 1u; tree.last[rc] = l; }
+            // the bigger child first, so that it is taken up last
+            const bool left_bigger = (mid - f) >= (l - mid - 1u);
+            const uint32_t a = left_bigger ? lc : rc, b = left_bigger ? rc : lc;
+            uint32_t w = sp;
+            for (const uint32_t c : {a, b}) {
+                if (c & lbvh::LEAF_BIT) continue;
+                s_stack[w][0] = c;
+                s_stack[w][1] = (c == lc) ? f : mid + 1u;
+                s_stack[w][2] = (c == lc) ? mid : l;
+                ++w;
+            }
+        }
+        sp += ((lc & lbvh::LEAF_BIT) ? 0u : 1u) + ((rc & lbvh::LEAF_BIT) ? 0u : 1u);
+        __threadfence_block();
+        __syncthreads();
+    }
+    flush_small();
+}
+
+// one thread per treelet (sequential binned-SAH rebuild, lbvh_core.h); 64-thread blocks: the threads' bins live in scratch
+__global__ void __launch_bounds__(64) k_treelet(lbvh::Tree tree, const uint32_t* __restrict__ roots, uint32_t n_roots, uint32_t* __restrict__ vals,
+                                                Box3* __restrict__ sbox, uint32_t* __restrict__ stack) {
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r < n_roots) lbvh::treelet_rebuild(tree, roots[r], vals, sbox, stack);
+}
+
+// inner nodes over more than max_leaf triangles: the bound on the 4-wide nodes the collapse can make
+__global__ void __launch_bounds__(BT) k_count_big(uint32_t n, lbvh::Tree tree, Globals* g) {
     __shared__ uint32_t s_big;
     if (threadIdx.x == 0) s_big = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * BT + threadIdx.x;
-    bool big = false;
-    if (i + 1 < n) {
-        lbvh::build_inner(keys, (int64_t)n, (int64_t)i, tree);
-        big = tree.last[i] - tree.first[i] + 1u > tree.max_leaf;
-    }
+    const bool big = (i + 1 < n) && tree.last[i] - tree.first[i] + 1u > tree.max_leaf;
     const unsigned long long m = __ballot(big);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_big, (uint32_t)__popcll(m));
     __syncthreads();
     if (threadIdx.x == 0 && s_big) atomicAdd(&g->n_big, s_big);   // one same-address atomic per workgroup
+}
+
+__global__ void __launch_bounds__(BT) k_sorted_boxes(const uint32_t* __restrict__ vals, const Box3* __restrict__ boxes, uint32_t n, Box3* __restrict__ out) {
+    const uint32_t s = blockIdx.x * BT + threadIdx.x;
+    if (s < n) out[s] = boxes[vals[s]];
 }
 
 // next level of the pairwise-union pyramid
@@ -262,11 +478,10 @@ __global__ void __launch_bounds__(BT) k_collapse(const uint2* __restrict__ q_in,
 __global__ void __launch_bounds__(BT) k_gather(const float* __restrict__ raw, const int32_t* __restrict__ matidx,
                                                const uint32_t* __restrict__ vals, uint32_t n_live, const MatRec* __restrict__ mats,
                                                uint32_t mat_base, uint32_t n_mats_obj, uint32_t tri_base, const Box3* __restrict__ boxes,
-                                               TriRec* __restrict__ out, Box3* __restrict__ sorted_boxes) {
+                                               TriRec* __restrict__ out) {
     const uint32_t s = blockIdx.x * BT + threadIdx.x;
     if (s >= n_live) return;
     const uint32_t t = vals[s];
-    sorted_boxes[s] = boxes[t];
     float f[24];
     load_raw(raw, t, f);
     float n[3], len;
@@ -451,23 +666,16 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
     BCK(tmp.get(&sort_tmp, sort_bytes));
     BCK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)nt, 0, 64, stream));
     const uint64_t* keys = keys_b;
-    const uint32_t* vals = vals_b;
+    uint32_t* vals = vals_b;
     mark("sort");
 
     TriRec* tris = nullptr;
-    Box3* pyr_base = nullptr;
-    lbvh::Pyramid pyr{};
-    const uint32_t pyr_total = lbvh::pyramid_layout(n, pyr.off, &pyr.levels);
     BCK(tmp.get(&tris, n));
-    BCK(tmp.get(&pyr_base, pyr_total));
-    pyr.base = pyr_base;
-    hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(BT), 0, stream, raw, matidx, vals, n, d_mats, mat_base, n_mats_obj, tri_base, boxes, tris,
-                       pyr_base);
-    BCK(hipGetLastError());
-
     uint32_t max_leaf = 2;   // measured: leaves of <= 2 trace 3-10 % faster than <= 4 (more, smaller boxes; as bvh.cpp's ALWAYS_LEAF)
     if (const char* e = std::getenv("TRR_LBVH_MAX_LEAF")) max_leaf = (uint32_t)std::min(4, std::max(1, std::atoi(e)));   // experiments
     if (n <= max_leaf) {   // the whole object is one leaf
+        hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(BT), 0, stream, raw, matidx, (const uint32_t*)vals, n, d_mats, mat_base, n_mats_obj, tri_base, boxes, tris);
+        BCK(hipGetLastError());
         BCK(hipStreamSynchronize(stream));
         out->root_ref = make_leaf_ref(slot_base, n);
         out->tris = tris;
@@ -481,9 +689,63 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
     BCK(tmp.get(&tree.first, n - 1));
     BCK(tmp.get(&tree.last, n - 1));
     BCK(tmp.get(&tree.ibox, n - 1));
-    tree.leaf_box = pyr_base;
     tree.max_leaf = max_leaf;
-    hipLaunchKernelGGL(k_hier, dim3(blocks_for(n - 1)), dim3(BT), 0, stream, keys, n, tree, g);
+    Box3* pyr_base = nullptr;
+    lbvh::Pyramid pyr{};
+    const uint32_t pyr_total = lbvh::pyramid_layout(n, pyr.off, &pyr.levels);
+    BCK(tmp.get(&pyr_base, pyr_total));
+    pyr.base = pyr_base;
+    tree.leaf_box = pyr_base;
+    // treelets (lbvh_core.h): subtrees of at most treelet_max triangles are rebuilt with SAH splits -- ranges above
+    // small_max by one wavefront each, the ranges below by one thread each.  0: plain radix tree.  Measured:
+    // 2048 / 8 brings the 4K frames of the three BASELINE meshes to within 0-3 % of the host SAH tree's for 3-10 ms.
+    uint32_t treelet_max = 2048, small_max = 8;
+    if (const char* e = std::getenv("TRR_TREELET_MAX")) treelet_max = (uint32_t)std::max(0, std::atoi(e));   // experiments
+    if (const char* e = std::getenv("TRR_TREELET_SMALL")) small_max = (uint32_t)std::max(3, std::atoi(e));
+    uint32_t *roots = nullptr, *big_roots = nullptr, *tl_stack = nullptr, *vals_tmp = nullptr;
+    Box3* sbox_tmp = nullptr;
+    const uint32_t roots_cap = n / 2 + 1;
+    if (treelet_max >= 3u) {
+        BCK(tmp.get(&roots, roots_cap));
+        BCK(tmp.get(&big_roots, roots_cap));
+        BCK(tmp.get(&tl_stack, n));
+        BCK(tmp.get(&vals_tmp, n));
+        BCK(tmp.get(&sbox_tmp, n));
+    }
+    // level 0 of the pyramid = the boxes in sorted order (the treelet pass permutes them together with vals)
+    hipLaunchKernelGGL(k_sorted_boxes, dim3(blocks_for(n)), dim3(BT), 0, stream, (const uint32_t*)vals, (const Box3*)boxes, n, pyr_base);
+    BCK(hipGetLastError());
+    hipLaunchKernelGGL(k_hier, dim3(blocks_for(n - 1)), dim3(BT), 0, stream, keys, n, tree, treelet_max, small_max, roots, big_roots, g);
+    BCK(hipGetLastError());
+    if (treelet_max >= 3u) {
+        BCK(hipMemcpyAsync(&h, g, sizeof h, hipMemcpyDeviceToHost, stream));
+        BCK(hipStreamSynchronize(stream));
+        if (h.n_roots > roots_cap || h.n_roots_big > roots_cap) {
+            if (err) *err = "device build: treelet count out of range";
+            return hipErrorUnknown;
+        }
+        mark("sorted boxes + radix tree");
+        if (h.n_roots_big) {
+            hipLaunchKernelGGL(k_treelet_top, dim3(h.n_roots_big), dim3(64), 0, stream, tree, (const uint32_t*)big_roots, h.n_roots_big, small_max, vals,
+                               pyr_base, vals_tmp, sbox_tmp, roots, roots_cap, g);
+            BCK(hipGetLastError());
+            BCK(hipMemcpyAsync(&h, g, sizeof h, hipMemcpyDeviceToHost, stream));
+            BCK(hipStreamSynchronize(stream));
+            if (h.n_roots > roots_cap) {
+                if (err) *err = "device build: treelet count out of range";
+                return hipErrorUnknown;
+            }
+            mark("big treelets");
+        }
+        if (h.n_roots) {
+            hipLaunchKernelGGL(k_treelet, dim3((h.n_roots + 63u) / 64u), dim3(64), 0, stream, tree, (const uint32_t*)roots, h.n_roots, vals, pyr_base, tl_stack);
+            BCK(hipGetLastError());
+        }
+        mark("small treelets");
+    }
+    hipLaunchKernelGGL(k_count_big, dim3(blocks_for(n - 1)), dim3(BT), 0, stream, n, tree, g);
+    BCK(hipGetLastError());
+    hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(BT), 0, stream, raw, matidx, (const uint32_t*)vals, n, d_mats, mat_base, n_mats_obj, tri_base, boxes, tris);
     BCK(hipGetLastError());
     {
         uint32_t m = n;
@@ -498,7 +760,7 @@ hipError_t build_object_device(const float* h_tris, const int32_t* h_matidx, uin
     BCK(hipGetLastError());
     BCK(hipMemcpyAsync(&h, g, sizeof h, hipMemcpyDeviceToHost, stream));
     BCK(hipStreamSynchronize(stream));
-    mark("gather + tree + fit");
+    mark("gather + fit");
     const uint32_t n_big = h.n_big;   // the root is one of them (n > max_leaf)
     if (n_big == 0 || n_big > n - 1) {
         if (err) *err = "device build: inner-node count out of range";

@@ -14,11 +14,14 @@ namespace trr {
 namespace {
 
 constexpr int MAX_BINS = 64;
-int NBINS = 16;              // (tunable for experiments: TRR_BVH_BINS = 4..64)
+int NBINS = 32;              // (tunable for experiments: TRR_BVH_BINS = 4..64)
 uint32_t SWEEP_MAX = 0;      // ranges of at most this many triangles are split by an exact SAH sweep (TRR_BVH_SWEEP)
 uint32_t MAX_LEAF = 4;       // (tunable for experiments: TRR_BVH_MAX_LEAF = 1..4)
 uint32_t ALWAYS_LEAF = 2;    // ranges of at most this many triangles are never split (TRR_BVH_ALWAYS_LEAF)
-float LEAF_BIAS = 1.5f;      // leaf preferred while leaf_cost <= split_cost + LEAF_BIAS * area (TRR_BVH_LEAF_BIAS)
+float LEAF_BIAS = 0.5f;      // leaf preferred while leaf_cost <= split_cost + LEAF_BIAS * area (TRR_BVH_LEAF_BIAS); round 3: 1.5 -> 0.5
+                             // and 16 -> 32 bins lower the wavefront steps per ray by 3 % (scripts/experiments/tree_quality.py)
+uint32_t MEDIAN_BELOW = 0;   // experiment (TRR_BVH_MEDIAN_BELOW): ranges of at most this many triangles are split at the spatial
+                             // middle of their widest axis, as a Morton-order build would, instead of by SAH
 constexpr uint32_t PAR_MIN = 1u << 15;   // subtrees above this size may get their own thread
 
 struct BNode {
@@ -158,7 +161,15 @@ struct Builder {
             if (best_axis < 0 || leaf_cost <= best_cost + LEAF_BIAS * half_area(box)) { make_leaf(nd, lo, hi); return; }
         }
         uint32_t mid = lo;
-        if (best_axis >= 0) {
+        if (cnt <= MEDIAN_BELOW) {
+            int ax = 0;
+            float e0 = cmax[0] - cmin[0], e1 = cmax[1] - cmin[1], e2 = cmax[2] - cmin[2];
+            if (e1 > e0 && e1 >= e2) ax = 1; else if (e2 > e0 && e2 > e1) ax = 2;
+            const float m = 0.5f * cmin[ax] + 0.5f * cmax[ax];
+            const std::vector<float>& ca = cent[ax];
+            auto it = std::partition(idx.begin() + lo, idx.begin() + hi, [&](uint32_t t) { return ca[t] < m; });
+            mid = (uint32_t)(it - idx.begin());
+        } else if (best_axis >= 0) {
             const float c0 = cmin[best_axis];
             const std::vector<float>& ca = cent[best_axis];
             auto it = std::partition(idx.begin() + lo, idx.begin() + hi, [&](uint32_t t) {
@@ -267,6 +278,7 @@ void build_bvh4(const Box3* boxes, uint32_t n, uint32_t n_threads, BuildResult* 
     if (const char* e = std::getenv("TRR_BVH_ALWAYS_LEAF")) ALWAYS_LEAF = (uint32_t)std::min(4, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("TRR_BVH_LEAF_BIAS")) LEAF_BIAS = (float)std::atof(e);
     if (const char* e = std::getenv("TRR_BVH_BINS")) NBINS = std::min(MAX_BINS, std::max(4, std::atoi(e)));
+    if (const char* e = std::getenv("TRR_BVH_MEDIAN_BELOW")) MEDIAN_BELOW = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("TRR_BVH_SWEEP")) SWEEP_MAX = (uint32_t)std::max(0, std::atoi(e));
     if (ALWAYS_LEAF > MAX_LEAF) ALWAYS_LEAF = MAX_LEAF;
     if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());

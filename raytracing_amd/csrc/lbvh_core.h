@@ -184,6 +184,112 @@ TRR_HD inline uint32_t leaf_ref_of(const Tree& t, uint32_t ref, uint32_t slot_ba
     return REF_LEAF | ((t.first[ref] + slot_base) << 2) | (t.last[ref] - t.first[ref]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Treelets: the bottom of the radix tree rebuilt with surface-area splits.  Measured on the host builder:
+// most of what a Morton-order tree loses against a SAH tree it loses in its small subtrees.  A subtree of at most
+// `treelet_max` triangles (a "treelet": a contiguous range [a, b] of the sorted order) is rebuilt by ONE thread, top-down,
+// by binned SAH over the three axes like bvh.cpp's Builder::build, permuting the range in place.  A rebuilt node still
+// covers a contiguous range, so the box fit and the collapse work on it unchanged, and it keeps Karras' numbering -- a left
+// child has the index of its last leaf, a right child of its first -- so the rebuilt subtree uses exactly the node slots of
+// the old one and needs no allocation.
+constexpr int TL_BINS = 8;
+
+TRR_HD inline float centroid_of(const Box3& b, int k) {
+    const float c = 0.5f * b.lo[k] + 0.5f * b.hi[k];
+    return (c - c == 0.0f) ? c : 0.0f;   // NaN / infinite vertices must not poison the binning (as bvh.cpp)
+}
+
+// vals / sbox: the sorted triangle ids and their boxes (both permuted together); stack: one word per sorted position, the
+// thread uses the slice [first, last] of its treelet.
+TRR_HD inline void treelet_rebuild(const Tree& t, uint32_t root, uint32_t* vals, Box3* sbox, uint32_t* stack) {
+    const float inf = __builtin_inff();
+    const uint32_t base = t.first[root];
+    uint32_t sp = 0;
+    stack[base + sp++] = root;
+    while (sp > 0) {
+        const uint32_t node = stack[base + --sp];
+        const uint32_t f = t.first[node], l = t.last[node], cnt = l - f + 1u;
+        uint32_t mid = f + (cnt - 1u) / 2u;   // last position of the left part; the default splits by count
+        if (cnt > 2u) {
+            float cmin[3] = {inf, inf, inf}, cmax[3] = {-inf, -inf, -inf};
+            for (uint32_t i = f; i <= l; ++i) {
+                const Box3 b = sbox[i];
+                for (int k = 0; k < 3; ++k) {
+                    const float c = centroid_of(b, k);
+                    cmin[k] = fmin_(cmin[k], c);
+                    cmax[k] = fmax_(cmax[k], c);
+                }
+            }
+            float best_cost = inf, best_scale = 0.0f;
+            int best_axis = -1, best_bin = -1;
+            for (int ax = 0; ax < 3; ++ax) {
+                const float ext = cmax[ax] - cmin[ax];
+                if (!(ext > 0.0f) || !(ext - ext == 0.0f)) continue;
+                const float scale = (float)TL_BINS / ext;
+                Box3 bb[TL_BINS];
+                uint32_t bc[TL_BINS];
+                for (int b = 0; b < TL_BINS; ++b) { bb[b] = Box3{{inf, inf, inf}, {-inf, -inf, -inf}}; bc[b] = 0; }
+                for (uint32_t i = f; i <= l; ++i) {
+                    const Box3 bx = sbox[i];
+                    int b = (int)((centroid_of(bx, ax) - cmin[ax]) * scale);
+                    b = b < 0 ? 0 : (b >= TL_BINS ? TL_BINS - 1 : b);
+                    bc[b]++;
+                    bb[b] = box_union(bb[b], bx);
+                }
+                float right_area[TL_BINS];
+                uint32_t right_cnt[TL_BINS];
+                Box3 acc{{inf, inf, inf}, {-inf, -inf, -inf}};
+                uint32_t c = 0;
+                for (int b = TL_BINS - 1; b > 0; --b) {
+                    acc = box_union(acc, bb[b]);
+                    c += bc[b];
+                    right_area[b] = box_half_area(acc);
+                    right_cnt[b] = c;
+                }
+                acc = Box3{{inf, inf, inf}, {-inf, -inf, -inf}};
+                c = 0;
+                for (int b = 0; b < TL_BINS - 1; ++b) {
+                    acc = box_union(acc, bb[b]);
+                    c += bc[b];
+                    if (c == 0 || right_cnt[b + 1] == 0) continue;
+                    const float cost = box_half_area(acc) * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; best_scale = scale; }
+                }
+            }
+            if (best_axis >= 0) {   // partition [f, l] in place: bins <= best_bin first
+                const float c0 = cmin[best_axis];
+                uint32_t i = f, j = l;
+                for (;;) {
+                    while (i <= j) {
+                        int b = (int)((centroid_of(sbox[i], best_axis) - c0) * best_scale);
+                        b = b < 0 ? 0 : (b >= TL_BINS ? TL_BINS - 1 : b);
+                        if (b > best_bin) break;
+                        ++i;
+                    }
+                    while (i < j) {
+                        int b = (int)((centroid_of(sbox[j], best_axis) - c0) * best_scale);
+                        b = b < 0 ? 0 : (b >= TL_BINS ? TL_BINS - 1 : b);
+                        if (b <= best_bin) break;
+                        --j;
+                    }
+                    if (i >= j) break;
+                    const Box3 tb = sbox[i]; sbox[i] = sbox[j]; sbox[j] = tb;
+                    const uint32_t tv = vals[i]; vals[i] = vals[j]; vals[j] = tv;
+                    ++i;
+                    --j;
+                }
+                if (i > f && i <= l) mid = i - 1u;   // (both sides non-empty: the cost loop skipped empty sides)
+            }
+        }
+        const uint32_t lc = (mid == f) ? (LEAF_BIT | f) : mid;
+        const uint32_t rc = (mid + 1u == l) ? (LEAF_BIT | l) : mid + 1u;
+        t.child_l[node] = lc;
+        t.child_r[node] = rc;
+        if (!(lc & LEAF_BIT)) { t.first[lc] = f; t.last[lc] = mid; stack[base + sp++] = lc; }
+        if (!(rc & LEAF_BIT)) { t.first[rc] = mid + 1u; t.last[rc] = l; stack[base + sp++] = rc; }
+    }
+}
+
 TRR_HD inline void node4_set_box(Node4& nd, int k, const Box3& bx) {
     nd.lox[k] = bx.lo[0]; nd.loy[k] = bx.lo[1]; nd.loz[k] = bx.lo[2];
     nd.hix[k] = bx.hi[0]; nd.hiy[k] = bx.hi[1]; nd.hiz[k] = bx.hi[2];

@@ -1,7 +1,10 @@
 // Runs the per-element bodies of the device BVH build (raytracing_amd/csrc/lbvh_core.h) serially on the CPU, in the
 // order of the kernels of build_device.hip, and checks the resulting 4-wide tree: every sorted position in exactly one
 // leaf, every child box containing every triangle box below it.  Built and run by tests/test_lbvh_core.py.
-//   usage: lbvh_core_check <n> <seed> <mode>     mode 0: uniform, 1: many identical centroids, 2: on a line, 3: clustered
+//   usage: lbvh_core_check <n> <seed> <mode> [treelet_max]   mode 0: uniform, 1: many identical centroids, 2: on a line,
+//   3: clustered, 4: the triangles of a tessellated bumpy sphere; treelet_max >= 3: subtrees of at most that many triangles
+//   are rebuilt by lbvh::treelet_rebuild (what k_treelet does; k_treelet_top, the wavefront form for big ranges, makes the
+//   same kind of tree and is checked on the GPU by trr_scene_validate in tests/test_gpu_build_device.py)
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +27,7 @@ int main(int argc, char** argv) {
     const uint32_t n = (uint32_t)std::atol(argv[1]);
     const uint32_t seed = (uint32_t)std::atol(argv[2]);
     const int mode = std::atoi(argv[3]);
+    const uint32_t treelet_max = argc > 4 ? (uint32_t)std::atol(argv[4]) : 0u;
     std::mt19937 rng(seed);
     std::uniform_real_distribution<float> U(-10.0f, 10.0f), S(0.0f, 0.3f);
     std::vector<Box3> boxes(n);
@@ -34,6 +38,20 @@ int main(int argc, char** argv) {
         if (mode == 3) { float k = (float)(i % 7); c[0] = k + 0.001f * c[0]; c[1] = k + 0.001f * c[1]; c[2] = 0.001f * c[2]; }
         float h = (mode == 1 && (i % 3)) ? 0.25f : S(rng);
         for (int k = 0; k < 3; ++k) { boxes[i].lo[k] = c[k] - h; boxes[i].hi[k] = c[k] + h; }
+    }
+    if (mode == 4) {   // boxes of the triangles of a (u, v) grid over a bumpy sphere, two per cell
+        const uint32_t nv = (uint32_t)std::max(2.0, std::sqrt(n / 4.0)), nu = std::max(3u, n / (2 * nv));
+        auto P = [&](uint32_t iu, uint32_t iv, float p[3]) {
+            const float u = 6.2831853f * (float)iu / (float)nu, v = 3.1415926f * (float)iv / (float)nv;
+            const float r = 5.0f + 0.4f * std::sin(7.0f * u) * std::sin(5.0f * v);
+            p[0] = r * std::sin(v) * std::cos(u); p[1] = r * std::cos(v); p[2] = r * std::sin(v) * std::sin(u);
+        };
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t cell = i / 2, iu = cell % nu, iv = (cell / nu) % nv;
+            float a[3], b[3], c[3];
+            if (i & 1) { P(iu, iv, a); P(iu + 1, iv, b); P(iu + 1, iv + 1, c); } else { P(iu, iv, a); P(iu + 1, iv + 1, b); P(iu, iv + 1, c); }
+            for (int k = 0; k < 3; ++k) { boxes[i].lo[k] = std::min({a[k], b[k], c[k]}); boxes[i].hi[k] = std::max({a[k], b[k], c[k]}) + 1e-4f; }
+        }
     }
     // k_prep / k_keys
     float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
@@ -79,6 +97,40 @@ int main(int argc, char** argv) {
     lbvh::Tree t{child_l.data(), child_r.data(), first.data(), last.data(), ibox.data(), pyr_store.data(), lbvh::MAX_LEAF};
     for (uint32_t i = 0; i + 1 < n; ++i) lbvh::build_inner(keys.data(), n, i, t);
     if (first[0] != 0 || last[0] != n - 1) return fail("root range", first[0], last[0]);
+    size_t n_treelets = 0;
+    if (treelet_max >= 3) {
+        // k_hier's second half (which children root a treelet), then k_treelet on every root
+        std::vector<uint32_t> roots, stack(n, 0);
+        for (uint32_t i = 0; i + 1 < n; ++i) {
+            const uint32_t f = first[i], l = last[i], cl = child_l[i], cr = child_r[i];
+            if (l - f + 1 > treelet_max) {
+                if (!(cl & lbvh::LEAF_BIT)) {
+                    uint32_t c = cl - f + 1;
+                    if (c != last[cl] - first[cl] + 1) return fail("left count", i);
+                    if (c >= 3 && c <= treelet_max) roots.push_back(cl);
+                }
+                if (!(cr & lbvh::LEAF_BIT)) {
+                    uint32_t c = l - cr + 1;
+                    if (c != last[cr] - first[cr] + 1) return fail("right count", i);
+                    if (c >= 3 && c <= treelet_max) roots.push_back(cr);
+                }
+            } else if (i == 0 && l - f + 1 >= 3) roots.push_back(0);
+        }
+        std::vector<uint32_t> f0(first), l0(last);
+        for (uint32_t r : roots) lbvh::treelet_rebuild(t, r, val.data(), pyr_store.data(), stack.data());
+        for (uint32_t r : roots)
+            if (first[r] != f0[r] || last[r] != l0[r]) return fail("treelet root range changed", r);
+        for (uint32_t s = 0; s < n; ++s)
+            if (std::memcmp(&pyr_store[s], &boxes[val[s]], sizeof(Box3)) != 0) return fail("boxes and ids permuted apart", s);
+        n_treelets = roots.size();
+        // the levels of the pyramid above the (permuted) sorted boxes
+        uint32_t m = n;
+        for (uint32_t k = 1; k < pyr.levels; ++k) {
+            uint32_t m2 = (m + 1) >> 1;
+            for (uint32_t j = 0; j < m2; ++j) pyr_store[pyr.off[k] + j] = lbvh::pyramid_pair(&pyr_store[pyr.off[k - 1]], m, j);
+            m = m2;
+        }
+    }
     std::vector<uint32_t> parents(n - 1, 0), leaf_parents(n, 0);
     for (uint32_t i = 0; i + 1 < n; ++i) {
         // children partition the range
@@ -104,6 +156,9 @@ int main(int argc, char** argv) {
         for (uint32_t s = first[i] + 1; s <= last[i]; ++s) e = lbvh::box_union(e, pyr_store[s]);
         if (std::memcmp(&e, &ibox[i], sizeof e) != 0) return fail("range union differs from the exact union", i);
     }
+    double cost_inner = 0.0;   // surface-area cost of the binary tree's inner nodes, in root areas (what the treelets lower)
+    for (uint32_t i = 0; i + 1 < n; ++i) cost_inner += lbvh::box_half_area(ibox[i]);
+    cost_inner /= lbvh::box_half_area(ibox[0]);
     // k_collapse, level by level
     uint32_t n_big = 0;
     for (uint32_t i = 0; i + 1 < n; ++i) n_big += (last[i] - first[i] + 1 > lbvh::MAX_LEAF);
@@ -171,7 +226,7 @@ int main(int argc, char** argv) {
     }
     for (uint32_t s = 0; s < n; ++s)
         if (!seen[s]) return fail("slot in no leaf", s);
-    std::printf("ok n=%u nodes=%u (bound %u) depth=%u leaves=%zu tris/leaf=%.2f\n", n, n_nodes, n_big, depth, leaves,
-                (double)tri_in_leaves / (double)leaves);
+    std::printf("ok n=%u nodes=%u (bound %u) depth=%u leaves=%zu tris/leaf=%.2f treelets=%zu inner_cost=%.2f\n", n, n_nodes, n_big, depth, leaves,
+                (double)tri_in_leaves / (double)leaves, n_treelets, cost_inner);
     return 0;
 }
