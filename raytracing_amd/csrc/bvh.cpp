@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <thread>
 
 namespace trr {
@@ -28,6 +29,7 @@ struct BNode {
     Box3 box;
     uint32_t left, right;    // children (valid when count == 0)
     uint32_t first, count;   // leaf range in idx (count > 0)
+    uint32_t range_first, range_count;   // the range of idx below the node, leaf or not (the collapse may close a small subtree into a leaf)
 };
 
 inline Box3 empty_box() {
@@ -79,6 +81,8 @@ struct Builder {
         }
         nd.box = box;
         uint32_t cnt = hi - lo;
+        nd.range_first = lo;
+        nd.range_count = cnt;
         if (cnt <= ALWAYS_LEAF) { make_leaf(nd, lo, hi); return; }
 
         // exact SAH sweep for small ranges: every split position of the centroid order on every axis
@@ -205,15 +209,73 @@ struct Builder {
     }
 };
 
+// Which (grand)children of a binary node become the <= 4 children of its 4-wide node.  Greedy: open the child with the
+// largest box until there are four.  Optimal (the default, after Ylitie et al. 2017, "Efficient Incoherent Ray
+// Traversal on GPUs Through Compressed Wide BVHs", section 3.1): minimise the expected number of wavefront steps, with a
+// subtree's box surface as the chance of entering it --
+//   T(b)    = cost of b's subtree when b fills ONE child slot = A(b) * leaf_steps(count) for a leaf, A(b) * C_NODE + G(b, 4) else
+//   G(b, k) = cheapest way to hand b's two children i + j <= k slots = min F(l, i) + F(r, j)
+//   F(b, k) = min(T(b), G(b, k)), F(b, 1) = T(b)
+// A leaf's cost counts the kernel's triangle steps (two triangles per step).
+int COLLAPSE_DP = 1;         // TRR_BVH_COLLAPSE=greedy for the old rule
+float C_TRI_STEP = 2.0f;     // cost of a triangle step relative to a node step (TRR_BVH_TRI_STEP; measured: 1.5-2 is flat, 1 is worse)
+
+struct CollapseDP {
+    const std::vector<BNode>& bn;
+    uint32_t n_nodes;
+    std::vector<float> T, G;   // G[3*b + (k-2)], k = 2..4
+    std::vector<uint8_t> closed;   // the node ends up as a leaf reference (a leaf of the binary tree, or a subtree closed here)
+    explicit CollapseDP(const std::vector<BNode>& b, uint32_t n) : bn(b), n_nodes(n), T(n), G((size_t)3 * n, 0.0f), closed(n, 0) {
+        for (uint32_t b_ = n; b_-- > 0;) {   // children were allocated after their parents: descending order is bottom-up
+            const BNode& nd = bn[b_];
+            const float a = half_area(nd.box);
+            if (nd.count > 0) { T[b_] = a * C_TRI_STEP * (float)((nd.count + 1) / 2); closed[b_] = 1; continue; }
+            for (int k = 2; k <= 4; ++k) {
+                float best = INFINITY;
+                for (int i = 1; i < k; ++i) best = std::fmin(best, F(nd.left, i) + F(nd.right, k - i));
+                G[(size_t)3 * b_ + (k - 2)] = best;
+            }
+            T[b_] = a + G[(size_t)3 * b_ + 2];
+            if (nd.range_count <= MAX_LEAF) {   // a small subtree may be closed into one leaf
+                const float as_leaf = a * C_TRI_STEP * (float)((nd.range_count + 1) / 2);
+                if (as_leaf <= T[b_]) { T[b_] = as_leaf; closed[b_] = 1; }
+            }
+        }
+    }
+    bool is_leaf(uint32_t b) const { return closed[b] != 0; }
+    float F(uint32_t b, int k) const {
+        if (k == 1 || closed[b]) return T[b];
+        return std::fmin(T[b], G[(size_t)3 * b + (k - 2)]);
+    }
+    // the slots b's subtree takes when it may use k of them
+    void assign(uint32_t b, int k, uint32_t* kids, int* nk) const {
+        if (k == 1 || closed[b] || T[b] <= G[(size_t)3 * b + (k - 2)]) { kids[(*nk)++] = b; return; }
+        split(b, k, kids, nk);
+    }
+    void split(uint32_t b, int k, uint32_t* kids, int* nk) const {
+        const BNode& nd = bn[b];
+        int bi = 1;
+        float best = INFINITY;
+        for (int i = 1; i < k; ++i) {
+            const float c = F(nd.left, i) + F(nd.right, k - i);
+            if (c < best) { best = c; bi = i; }
+        }
+        assign(nd.left, bi, kids, nk);
+        assign(nd.right, k - bi, kids, nk);
+    }
+};
+
 struct Collapser {
     const std::vector<BNode>& bn;
     std::vector<Node4>& out;
+    const CollapseDP* dp = nullptr;
     uint32_t max_depth = 0;
     uint32_t stack_need = 0;
 
     uint32_t ref_of(uint32_t b, uint32_t depth, uint32_t pushed) {
         const BNode& nd = bn[b];
         if (nd.count > 0) return make_leaf_ref(nd.first, nd.count);
+        if (dp && dp->is_leaf(b)) return make_leaf_ref(nd.range_first, nd.range_count);
         return emit(b, depth, pushed);
     }
 
@@ -227,7 +289,11 @@ struct Collapser {
         int nk = 2;
         kids[0] = bn[b].left;
         kids[1] = bn[b].right;
-        while (nk < 4) {
+        if (dp) {
+            nk = 0;
+            dp->split(b, 4, kids, &nk);
+        }
+        while (!dp && nk < 4) {
             int pick = -1;
             float pa = -1.0f;
             for (int k = 0; k < nk; ++k) {
@@ -279,6 +345,8 @@ void build_bvh4(const Box3* boxes, uint32_t n, uint32_t n_threads, BuildResult* 
     if (const char* e = std::getenv("TRR_BVH_LEAF_BIAS")) LEAF_BIAS = (float)std::atof(e);
     if (const char* e = std::getenv("TRR_BVH_BINS")) NBINS = std::min(MAX_BINS, std::max(4, std::atoi(e)));
     if (const char* e = std::getenv("TRR_BVH_MEDIAN_BELOW")) MEDIAN_BELOW = (uint32_t)std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("TRR_BVH_COLLAPSE")) COLLAPSE_DP = std::strcmp(e, "dp") == 0;
+    if (const char* e = std::getenv("TRR_BVH_TRI_STEP")) C_TRI_STEP = (float)std::atof(e);
     if (const char* e = std::getenv("TRR_BVH_SWEEP")) SWEEP_MAX = (uint32_t)std::max(0, std::atoi(e));
     if (ALWAYS_LEAF > MAX_LEAF) ALWAYS_LEAF = MAX_LEAF;
     if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
@@ -310,6 +378,15 @@ void build_bvh4(const Box3* boxes, uint32_t n, uint32_t n_threads, BuildResult* 
     }
     res->nodes.reserve((size_t)n / 2 + 16);
     Collapser c{b.nodes, res->nodes};
+    std::unique_ptr<CollapseDP> dp;
+    if (COLLAPSE_DP) {
+        dp.reset(new CollapseDP(b.nodes, b.n_nodes.load()));
+        c.dp = dp.get();
+    }
+    if (dp && dp->is_leaf(0)) {   // (n <= MAX_LEAF and one leaf is cheapest)
+        res->root_ref = make_leaf_ref(b.nodes[0].range_first, b.nodes[0].range_count);
+        return;
+    }
     res->root_ref = c.emit(0, 1, 0);
     res->max_depth = c.max_depth;
     res->stack_need = c.stack_need;
