@@ -99,6 +99,32 @@ def test_small_dead_and_duplicate_triangles(ctx, oracle_mod):
     assert sorted(set(np.unique(out["device"][0]["hit_obj"]).tolist()) - {0xFFFFFFFF}) == [0, 2, 3, 4]
 
 
+@pytest.mark.parametrize("knobs", [{"TRR_TREELET_MAX": "0"}, {"TRR_TREELET_MAX": "64", "TRR_TREELET_SMALL": "64"},
+                                   {"TRR_TREELET_MAX": "100000", "TRR_TREELET_SMALL": "3"}, {"TRR_TREELET_MAX": "300", "TRR_TREELET_SMALL": "16"}])
+def test_treelet_settings_all_give_a_valid_tree_and_the_same_image(ctx, monkeypatch, knobs):
+    """The device build rebuilds small subtrees of its radix tree with SAH splits (lbvh_core.h): with the pass off, with
+    threads only (every treelet at most `small`), with wavefronts doing nearly everything (one treelet for a whole object,
+    ranges down to 3), and in between -- the tree validates and the image is the host-built tree's."""
+    scenes = [standin.standin_test(320, 240, n_car=60_000, n_floor=9_000), standin.standin_terrain(240, 160, nx=150, nz=90)]
+    for sc in scenes:
+        rt = Raytracer(sc, max_depth=3, context=ctx, build="host")
+        try:
+            want = rt.render_frame(want_ids=True)
+        finally:
+            rt.close()
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        rt = Raytracer(sc, max_depth=3, context=ctx, build="device")
+        try:
+            rt.validate()
+            got = rt.render_frame(want_ids=True)
+        finally:
+            rt.close()
+        for k in knobs:
+            monkeypatch.delenv(k)
+        assert np.array_equal(want["hit_tri"], got["hit_tri"]) and np.array_equal(want["rgb"], got["rgb"]), knobs
+
+
 def test_million_triangle_build_validates_and_renders_the_same(ctx):
     """The benchmark's mesh (BASELINE.json configs[1], 1.03 M triangles): device-built tree checked on the host, and a
     quarter-size frame identical to the host-built one."""
