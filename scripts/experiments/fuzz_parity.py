@@ -26,6 +26,8 @@ ENVS = [
     {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "0", "TRR_DRAIN_LEVEL": "1"}, {"TRR_SCHEDULE": "levels", "TRR_SPLIT": "1", "TRR_SHADOW": "wide"},
     {"TRR_CAMCULL": "0"}, {"TRR_SCHEDULE": "persistent", "TRR_CAMCULL": "0"}, {"TRR_SCHEDULE": "levels", "TRR_STAGE": "1"},
     {"TRR_SCHEDULE": "levels", "TRR_STAGE": "1", "TRR_SPLIT": "1"},
+    {"TRR_BVH_COLLAPSE": "greedy"}, {"TRR_TREELET_MAX": "0"}, {"TRR_TREELET_MAX": "40", "TRR_TREELET_SMALL": "40"},
+    {"TRR_TREELET_MAX": "100000", "TRR_TREELET_SMALL": "3"}, {"TRR_SPLIT_DRAIN": "1"},
 ]
 KEYS = sorted({k for e in ENVS for k in e})
 ctx = Context(0)
@@ -45,7 +47,8 @@ for case in range(n_cases):
     for k in KEYS:
         os.environ.pop(k, None)
     os.environ.update(env)
-    rt = Raytracer(sc, max_depth=md, context=ctx)
+    build = "device" if (case % 3 == 2 or any(k.startswith("TRR_TREELET") for k in env)) else "host"   # both BVH builders
+    rt = Raytracer(sc, max_depth=md, context=ctx, build=build)
     out = rt.render_frame(want_ids=spp == 1)
     rt.close()
     osc = oracle.OracleScene(sc)
@@ -55,7 +58,7 @@ for case in range(n_cases):
     ids = 1.0 if spp > 1 else float(((out["hit_obj"] == ref["hit_obj"]) & (out["hit_tri"] == ref["hit_tri"])).mean())
     ok = (d <= 1).mean() >= 0.999 and ids >= 0.9999
     bad += 0 if ok else 1
-    print(f"case {case:2d} {w}x{h} spp {spp:2d} depth {md} cam dist {dist:4.1f} env {env or 'default'}: exact {float((d == 0).mean()):.6f} "
+    print(f"case {case:2d} {w}x{h} spp {spp:2d} depth {md} cam dist {dist:4.1f} build {build} env {env or 'default'}: exact {float((d == 0).mean()):.6f} "
           f"within1 {float((d <= 1).mean()):.6f} max {int(d.max())} ids {ids:.6f} {'ok' if ok else 'FAIL'}", flush=True)
 ctx.close()
 print("failures:", bad)
