@@ -27,6 +27,17 @@ static_assert(sizeof(Node4) == 128, "Node4 must be one cache line");
 // The same node in 64 bytes, what the trace kernels read when the scene allows it (kernels.hip: k_quantise_nodes): the child
 // boxes as 8-bit offsets from the node's own lower corner, in units of a per-axis power of two, rounded OUTWARDS -- child
 // k spans [org + qlo_k * s, org + qhi_k * s] per axis, a superset of its Node4 box.  Byte k of each q word is child k.
+#ifdef TRR_WIDE8
+// experiment (-DTRR_WIDE8, scripts/experiments/build_wide8.sh): the slot of the quantised nodes holds an 8-WIDE exact node instead --
+// a Node4 with its largest inner children opened while the result has at most eight children (kernels.hip: k_quantise_nodes).
+// Node i of this array stands for the same subtree as Node4 i, so references stay what they are.
+struct alignas(128) QNode4 {
+    float lox[8], loy[8], loz[8], hix[8], hiy[8], hiz[8];
+    uint32_t child[8];
+    uint32_t pad[8];
+};
+static_assert(sizeof(QNode4) == 256, "the 8-wide node is two cache lines");
+#else
 struct alignas(64) QNode4 {
     float org[3];
     float sx;
@@ -36,6 +47,7 @@ struct alignas(64) QNode4 {
     uint32_t child[4];
 };
 static_assert(sizeof(QNode4) == 64, "QNode4 must be half a cache line");
+#endif
 
 constexpr uint32_t REF_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t REF_LEAF = 0x80000000u;

@@ -1862,6 +1862,64 @@ __global__ void __launch_bounds__(256) k_assemble(uint32_t width, uint32_t heigh
 // node's extent, so org / step < 2^32).  *flag is set when a node cannot be quantised -- a bound that is not finite or
 // above 2^20 in magnitude -- and the scene then keeps to its exact nodes.
 // ------------------------------------------------------------------------------------------------
+#ifdef TRR_WIDE8
+__global__ void __launch_bounds__(256) k_quantise_nodes(const Node4* __restrict__ nodes, QNode4* __restrict__ out, uint32_t n,
+                                                        uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float lo[8][3], hi[8][3];
+    uint32_t ch[8];
+    int nk = 0;
+    auto take = [&](const Node4& nd, int k, int at) {
+        lo[at][0] = nd.lox[k]; lo[at][1] = nd.loy[k]; lo[at][2] = nd.loz[k];
+        hi[at][0] = nd.hix[k]; hi[at][1] = nd.hiy[k]; hi[at][2] = nd.hiz[k];
+        ch[at] = nd.child[k];
+    };
+    {
+        const Node4 nd = nodes[i];
+        for (int k = 0; k < 4; ++k)
+            if (nd.child[k] != REF_EMPTY) take(nd, k, nk++);
+    }
+    for (;;) {   // open the inner child with the largest box whose children still fit
+        int pick = -1;
+        float pa = -1.0f;
+        for (int k = 0; k < nk; ++k) {
+            if (ch[k] >= REF_LEAF) continue;
+            const Node4& c = nodes[ch[k]];
+            int m = 0;
+            for (int j = 0; j < 4; ++j) m += c.child[j] != REF_EMPTY ? 1 : 0;
+            if (m == 0 || nk - 1 + m > 8) continue;
+            const float dx = hi[k][0] - lo[k][0], dy = hi[k][1] - lo[k][1], dz = hi[k][2] - lo[k][2];
+            float a = dx * dy + dy * dz + dz * dx;
+            if (!(a >= 0.0f)) a = 0.0f;
+            if (a > pa) { pa = a; pick = k; }
+        }
+        if (pick < 0) break;
+        const Node4 c = nodes[ch[pick]];
+        bool first = true;
+        for (int j = 0; j < 4; ++j) {
+            if (c.child[j] == REF_EMPTY) continue;
+            if (first) { take(c, j, pick); first = false; }
+            else take(c, j, nk++);
+        }
+    }
+    QNode4 q;
+    for (int k = 0; k < 8; ++k) {
+        if (k < nk) {
+            q.lox[k] = lo[k][0]; q.loy[k] = lo[k][1]; q.loz[k] = lo[k][2];
+            q.hix[k] = hi[k][0]; q.hiy[k] = hi[k][1]; q.hiz[k] = hi[k][2];
+            q.child[k] = ch[k];
+        } else {
+            q.lox[k] = q.loy[k] = q.loz[k] = INFINITY;
+            q.hix[k] = q.hiy[k] = q.hiz[k] = INFINITY;
+            q.child[k] = REF_EMPTY;
+        }
+        q.pad[k] = 0;
+    }
+    out[i] = q;
+    (void)flag;
+}
+#else
 __global__ void __launch_bounds__(256) k_quantise_nodes(const Node4* __restrict__ nodes, QNode4* __restrict__ out, uint32_t n,
                                                         uint32_t* __restrict__ flag) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -1914,6 +1972,7 @@ __global__ void __launch_bounds__(256) k_quantise_nodes(const Node4* __restrict_
     if (bad) atomicOr(flag, 1u);
 }
 
+#endif
 void launch_quantise_nodes(hipStream_t st, const Node4* nodes, QNode4* out, uint32_t n, uint32_t* flag) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_quantise_nodes, dim3((n + 255) / 256), dim3(256), 0, st, nodes, out, n, flag);

@@ -37,6 +37,74 @@
                 }
                 float t0, t1, t2, t3;
                 uint32_t r0, r1, r2, r3;
+#ifdef TRR_WIDE8
+                if constexpr (QN) {
+                    // experiment: 8-wide exact node (bvh.h), fourteen 16-B loads, eight slab tests, 19-comparator sort, up to seven pushes
+                    if (COUNT) c_boxes += 4;
+                    const float4* nd = reinterpret_cast<const float4*>(g_qnodes + cur);
+                    const float4 lxa = nd[0], lxb = nd[1], lya = nd[2], lyb = nd[3], lza = nd[4], lzb = nd[5];
+                    const float4 hxa = nd[6], hxb = nd[7], hya = nd[8], hyb = nd[9], hza = nd[10], hzb = nd[11];
+                    const uint4 cha = *reinterpret_cast<const uint4*>(nd + 12), chb = *reinterpret_cast<const uint4*>(nd + 13);
+                    float t4, t5, t6, t7;
+                    uint32_t r4, r5, r6, r7;
+#define TRR_BOX(T, R, LX, LY, LZ, HX, HY, HZ, CH)                                                          \
+    {                                                                                                      \
+        float ax = ((LX) - oo.x) * oi.x, bx = ((HX) - oo.x) * oi.x;                                        \
+        float ay = ((LY) - oo.y) * oi.y, by = ((HY) - oo.y) * oi.y;                                        \
+        float az = ((LZ) - oo.z) * oi.z, bz = ((HZ) - oo.z) * oi.z;                                        \
+        float tmin = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmin(az, bz));                                 \
+        float tmax = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmax(az, bz));                                 \
+        bool hit = (tmax > rmax(tmin, 0.0f)) & !(tmin > lim_n);                                            \
+        T = hit ? tmin : INFINITY;                                                                         \
+        R = hit ? (CH) : REF_EMPTY;                                                                        \
+    }
+                    TRR_BOX(t0, r0, lxa.x, lya.x, lza.x, hxa.x, hya.x, hza.x, cha.x)
+                    TRR_BOX(t1, r1, lxa.y, lya.y, lza.y, hxa.y, hya.y, hza.y, cha.y)
+                    TRR_BOX(t2, r2, lxa.z, lya.z, lza.z, hxa.z, hya.z, hza.z, cha.z)
+                    TRR_BOX(t3, r3, lxa.w, lya.w, lza.w, hxa.w, hya.w, hza.w, cha.w)
+                    TRR_BOX(t4, r4, lxb.x, lyb.x, lzb.x, hxb.x, hyb.x, hzb.x, chb.x)
+                    TRR_BOX(t5, r5, lxb.y, lyb.y, lzb.y, hxb.y, hyb.y, hzb.y, chb.y)
+                    TRR_BOX(t6, r6, lxb.z, lyb.z, lzb.z, hxb.z, hyb.z, hzb.z, chb.z)
+                    TRR_BOX(t7, r7, lxb.w, lyb.w, lzb.w, hxb.w, hyb.w, hzb.w, chb.w)
+#undef TRR_BOX
+#define TRR_CSWAP(TI, RI, TJ, RJ)                                                  \
+    {                                                                              \
+        bool sw_ = TJ < TI;                                                        \
+        float ta_ = sw_ ? TJ : TI, tb_ = sw_ ? TI : TJ;                            \
+        uint32_t ra_ = sw_ ? RJ : RI, rb_ = sw_ ? RI : RJ;                         \
+        TI = ta_; TJ = tb_; RI = ra_; RJ = rb_;                                    \
+    }
+                    // a NaN tmin (kept child) compares false both ways and may end up anywhere; the pushes below therefore test
+                    // every entry instead of relying on "hits first"
+                    TRR_CSWAP(t0, r0, t1, r1) TRR_CSWAP(t2, r2, t3, r3) TRR_CSWAP(t4, r4, t5, r5) TRR_CSWAP(t6, r6, t7, r7)
+                    TRR_CSWAP(t0, r0, t2, r2) TRR_CSWAP(t1, r1, t3, r3) TRR_CSWAP(t4, r4, t6, r6) TRR_CSWAP(t5, r5, t7, r7)
+                    TRR_CSWAP(t1, r1, t2, r2) TRR_CSWAP(t5, r5, t6, r6)
+                    TRR_CSWAP(t0, r0, t4, r4) TRR_CSWAP(t1, r1, t5, r5) TRR_CSWAP(t2, r2, t6, r6) TRR_CSWAP(t3, r3, t7, r7)
+                    TRR_CSWAP(t2, r2, t4, r4) TRR_CSWAP(t3, r3, t5, r5)
+                    TRR_CSWAP(t1, r1, t2, r2) TRR_CSWAP(t3, r3, t4, r4) TRR_CSWAP(t5, r5, t6, r6)
+#undef TRR_CSWAP
+                    if (sp + 7 <= STACK_LDS) {
+                        int at = sp;
+                        s_stack[at * TRACE_THREADS + tid] = make_uint2(r7, __float_as_uint(t7)); at += (r7 != REF_EMPTY ? 1 : 0);
+                        s_stack[at * TRACE_THREADS + tid] = make_uint2(r6, __float_as_uint(t6)); at += (r6 != REF_EMPTY ? 1 : 0);
+                        s_stack[at * TRACE_THREADS + tid] = make_uint2(r5, __float_as_uint(t5)); at += (r5 != REF_EMPTY ? 1 : 0);
+                        s_stack[at * TRACE_THREADS + tid] = make_uint2(r4, __float_as_uint(t4)); at += (r4 != REF_EMPTY ? 1 : 0);
+                        s_stack[at * TRACE_THREADS + tid] = make_uint2(r3, __float_as_uint(t3)); at += (r3 != REF_EMPTY ? 1 : 0);
+                        s_stack[at * TRACE_THREADS + tid] = make_uint2(r2, __float_as_uint(t2)); at += (r2 != REF_EMPTY ? 1 : 0);
+                        s_stack[at * TRACE_THREADS + tid] = make_uint2(r1, __float_as_uint(t1)); at += (r1 != REF_EMPTY ? 1 : 0);
+                        sp = at;
+                    } else {
+                        if (r7 != REF_EMPTY) push(r7, t7);
+                        if (r6 != REF_EMPTY) push(r6, t6);
+                        if (r5 != REF_EMPTY) push(r5, t5);
+                        if (r4 != REF_EMPTY) push(r4, t4);
+                        if (r3 != REF_EMPTY) push(r3, t3);
+                        if (r2 != REF_EMPTY) push(r2, t2);
+                        if (r1 != REF_EMPTY) push(r1, t1);
+                    }
+                    cur = (r0 != REF_EMPTY) ? r0 : pop();
+                } else
+#endif
                 if constexpr (QN) {
                     // ---- 64-B node (bvh.h QNode4): four 16-B loads per lane instead of seven.  Child k spans
                     // [org + qlo_k s, org + qhi_k s] per axis, a superset of its exact box; the slab distances come out of
@@ -145,6 +213,11 @@
                     TRR_BOX(t3, r3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
 #undef TRR_BOX
                 }
+#ifdef TRR_WIDE8
+                if constexpr (!QN) {
+#else
+                {
+#endif
                 // sort the four (tmin, ref) pairs ascending: 5-comparator network of selects
 #define TRR_CSWAP(TI, RI, TJ, RJ)                                                  \
     {                                                                              \
@@ -170,6 +243,7 @@
                     if (r1 != REF_EMPTY) push(r1, t1);
                 }
                 cur = (r0 != REF_EMPTY) ? r0 : pop();
+                }
             }
         } else if (m_leaf != 0ull) {
             // ---- leaf: own-box test + exact test of the leaf's next TRR_TRIS_PER_STEP remaining triangles ------------
