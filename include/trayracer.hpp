@@ -202,7 +202,8 @@ private:
 // Raytracer::new(scene, delta, max_depth) (raytracer/mod.rs:37): uploads a flattened copy of the scene (the reference
 // deep-clones it, render.rs:60) and renders it with the gfx950 kernels.  One render at a time per Context.
 // Where the BVH that stands in for bvh::Bvh::build (object.rs:156) is built: Host = binned SAH on the CPU cores (best
-// tree), Device = LBVH on the GPU (an order of magnitude faster to build; for scenes edited between renders).
+// tree), Device = Morton-order tree with SAH-rebuilt treelets on the GPU (an order of magnitude faster to build, frames within a
+// few per cent of the host tree's; for scenes edited between renders).
 enum class Build : uint32_t { Host = TRR_BUILD_HOST, Device = TRR_BUILD_DEVICE };
 
 class Raytracer {

@@ -167,12 +167,13 @@ void trr_scene_destroy(trr_scene* scene);
 
 /* The same with the BVH built where `build` says.  The reference rebuilds an object's Bvh on the CPU whenever the UI
  * adds an object (object.rs:156 via ui/properties.rs:307-415); TRR_BUILD_DEVICE does the whole flattening on the GPU
- * (Morton keys, radix sort, radix tree, box fit, 4-wide collapse: tens of milliseconds for 10 M triangles instead of
- * seconds), at the price of a tree that traces slower than the host's SAH tree.  Both builders produce the same
+ * (Morton keys, radix sort, radix tree with its subtrees of up to 2048 triangles rebuilt by SAH splits, box fit, 4-wide
+ * collapse: tens of milliseconds for 10 M triangles instead of seconds) for a tree whose frames are within a few per
+ * cent of the host SAH tree's.  Both builders produce the same
  * triangle / interpolation records, and -- because the closest hit is a min over every triangle whose own box the ray
  * passes (object.rs:191-206), whatever the tree -- the same image. */
 #define TRR_BUILD_HOST 0u     /* binned-SAH build on the host cores (what trr_scene_create does) */
-#define TRR_BUILD_DEVICE 1u   /* LBVH build on the GPU */
+#define TRR_BUILD_DEVICE 1u   /* Morton-order build on the GPU, SAH-rebuilt treelets */
 int trr_scene_create_ex(trr_ctx* ctx, const trr_object_desc* objects, uint32_t n_objects,
                         const trr_image_rgb8* textures, uint32_t n_textures, uint32_t build, trr_scene** out);
 

@@ -109,8 +109,8 @@ class Raytracer:
 
     def __init__(self, scene: Scene, delta: float = DEFAULT_DELTA, max_depth: int = DEFAULT_MAX_DEPTH,
                  context: Optional[Context] = None, device: int = 0, build: str = "host"):
-        """``build``: "host" = binned-SAH BVH on the host cores (best tree), "device" = LBVH on the GPU (fastest
-        upload; for scenes that change between renders).  Same image either way (include/trayracer_hip.h)."""
+        """``build``: "host" = binned-SAH BVH on the host cores (best tree), "device" = Morton-order tree with SAH-rebuilt
+        treelets on the GPU (fastest upload, frames within a few per cent; for scenes that change between renders).  Same image either way (include/trayracer_hip.h)."""
         if build not in ("host", "device"):
             raise ValueError("build must be 'host' or 'device'")
         self.build = build
