@@ -125,6 +125,33 @@ def test_treelet_settings_all_give_a_valid_tree_and_the_same_image(ctx, monkeypa
         assert np.array_equal(want["hit_tri"], got["hit_tri"]) and np.array_equal(want["rgb"], got["rgb"]), knobs
 
 
+def test_treelets_of_identical_and_collinear_triangles(ctx):
+    """What the SAH splits of the treelet pass cannot separate: thousands of identical triangles (no centroid extent on any
+    axis: the ranges are halved by count), centroids on one line, and a big triangle over many small ones (one bin takes
+    nearly everything) -- each well above the wavefront stage's range size, in one object and in objects of their own."""
+    rng = np.random.default_rng(5)
+    z = -4.0
+    same = np.repeat(tri_rows(((-1.5, -1.0, z), (-0.5, -1.0, z), (-1.0, 0.0, z))), 5000, axis=0)
+    xs = np.linspace(-1.9, 1.9, 6000)
+    line = np.concatenate([tri_rows(((x, 0.6, z + 0.5), (x + 0.0005, 0.6, z + 0.5), (x + 0.00025, 0.9, z + 0.5))) for x in xs])
+    small = []
+    for _ in range(4000):
+        cx, cy = rng.uniform(0.2, 1.8), rng.uniform(-1.2, 0.2)
+        small.append(((cx, cy, z + 1.0), (cx + 0.01, cy, z + 1.0), (cx, cy + 0.01, z + 1.0)))
+    big = tri_rows(((0.0, -1.5, z + 0.2), (2.0, -1.5, z + 0.2), (1.0, 0.5, z + 0.2)), *small)
+    m = [mat(kd=(0.7, 0.5, 0.3), illum=2, ks=(1, 1, 1), ns=9.0, dissolve=0.0)]
+
+    def obj(t):
+        return Object(triangles=t, material_index=np.zeros(len(t), np.int32), materials=m)
+    everything = np.concatenate([same, line, big])
+    for name, objs in [("one object", [obj(everything)]), ("three objects", [obj(same), obj(line), obj(big)])]:
+        sc = Scene(objects=objs, lights=[Light(np.array([0.5, 2.0, 0], F32), np.array([1, 1, 1], F32), 9.0)],
+                   camera=front_camera(160, 120), settings=Settings())
+        out = render_both(ctx, sc, max_depth=2)
+        assert_same(out, name)
+        assert out["device"][1]["bvh_depth"] < 64, out["device"][1]
+
+
 def test_million_triangle_build_validates_and_renders_the_same(ctx):
     """The benchmark's mesh (BASELINE.json configs[1], 1.03 M triangles): device-built tree checked on the host, and a
     quarter-size frame identical to the host-built one."""
