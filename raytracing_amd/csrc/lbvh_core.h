@@ -156,7 +156,8 @@ TRR_HD inline Box3 ref_box(const Tree& t, uint32_t ref) {
 }
 
 // Children of the 4-wide node rooted at binary inner node b: its two children, then repeatedly the child with the
-// largest box that is not leaf-like is replaced by its own two children (same rule as bvh.cpp's Collapser).
+// largest box that is not leaf-like is replaced by its own two children (bvh.cpp's greedy rule; its default, a dynamic
+// programme over the whole binary tree, needs a bottom-up pass that this top-down, level-by-level collapse does not have).
 // Returns the number of children (2..4) and fills kids[] with binary-tree references.
 TRR_HD inline int collapse_children(const Tree& t, uint32_t b, uint32_t kids[4]) {
     int nk = 2;
